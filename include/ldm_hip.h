@@ -1,0 +1,212 @@
+/*
+ * ldm_hip.h -- C ABI of libldm_hip.so: hand-written HIP kernels (gfx950 / MI355X)
+ * for the latent-diffusion SAMPLING path of chao-ji/ldm_tf2.
+ *
+ * The reference has no FFI/plugin interface (it is pure Python on TensorFlow;
+ * SURVEY.md section 8b), so this ABI is build-defined.  Each entry point names the
+ * reference call site(s) whose arithmetic it replaces.  Conventions:
+ *   - extern "C", plain pointers and sizes, no torch / C++ types;
+ *   - every pointer is a DEVICE pointer unless it says "host";
+ *   - the library never allocates, frees or synchronises; every kernel is
+ *     enqueued on the caller's `stream` (a hipStream_t passed as void*), so the
+ *     caller may capture any sequence of calls into a HIP graph;
+ *   - return value: 0 = ok, negative = error (ldm_last_error() has the text);
+ *   - activations are NHWC ("pixel rows" of C channels, explicit pixel stride
+ *     `ld*` in ELEMENTS so a tensor may be a channel slice of a wider buffer:
+ *     that is how the U-Net skip concatenation (unet.py:135) costs nothing);
+ *   - dtype: 0 = float32, 1 = bfloat16 (storage; accumulation, statistics,
+ *     softmax and the DDIM scheduler are always float32);
+ *   - biases / gammas / betas / per-row addends are always float32.
+ */
+#ifndef LDM_HIP_H
+#define LDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDM_F32 0
+#define LDM_BF16 1
+
+#define LDM_OK 0
+#define LDM_ERR_ARG (-1)
+#define LDM_ERR_LAUNCH (-2)
+#define LDM_ERR_WORKSPACE (-3)
+
+/* epilogue activations of ldm_gemm */
+#define LDM_ACT_NONE 0
+#define LDM_ACT_GELU 1  /* exact erf gelu: transformer.py:169 (tf.nn.gelu)        */
+#define LDM_ACT_GEGLU 2 /* value*gelu(gate): unet.py:323-325; weight rows interleaved
+                           in blocks of 64 = 32 value rows then their 32 gate rows  */
+#define LDM_ACT_SILU 3  /* unet.py:72 Dense(activation="silu")                     */
+
+int ldm_version(void);
+/* copies the calling thread's last error text into buf (host), returns its length */
+int ldm_last_error(char* buf, int n);
+
+/*
+ * Dense / 1x1-conv / attention-projection GEMM and implicit-GEMM 3x3 convolution.
+ *
+ *   out[b][m][n] = act( alpha * sum_k A[b][m][k] * Wt[b][n][k] + bias[n]
+ *                       + addend[(m / add_rows) * add_ld + n] ) + residual[b][m][n]
+ *
+ * A rows are K-contiguous; Wt is the weight matrix stored [N][K] (K contiguous),
+ * i.e. the TRANSPOSE of the reference's Dense kernel [in,out] / the OHWI form of
+ * its HWIO conv kernel -- the host re-lays weights out once at load time.
+ *
+ * conv = 1: A is gathered on the fly from an NHWC image [B][H][W][Cin] (pixel
+ *   stride lda): m = (b, oy, ox) over [B][OH][OW], k = (kh, kw, ci) over 3x3xCin,
+ *   source pixel (oy*stride + kh - 1, ox*stride + kw - 1), zero outside; with
+ *   upsample = 1 the source image is first nearest-2x upsampled
+ *   (src[i][j] = img[i/2][j/2]).  Cin must be a multiple of 128/sizeof(elem).
+ *   Replaces: Conv2D 3x3 SAME (unet.py:22,40,71,375,378; autoencoder.py:32,35,
+ *   148,275), pad(1,1)+stride-2 VALID (unet.py:26-27), ResizeNearestNeighbor+conv
+ *   (unet.py:44-47, autoencoder.py:152-155).
+ * conv = 0: plain rows.  Replaces Dense (unet.py:72-73,320,332,350,353,376,379;
+ *   autoencoder.py:36,69-72; transformer.py:137-138), Projection einsums
+ *   (transformer.py:68,70) and, batched, the materialised attention einsums of
+ *   autoencoder.py:86,93.
+ *
+ * Output element (m, n) of batch b is stored at out + b*stride_c + m*ldc_m + n*ldc_n
+ * (ldc_n = 1 for row-major; ldc_m = 1 gives the transposed store used for V^T).
+ * With LDM_ACT_GEGLU the stored width is N/2.
+ * split_k > 1 needs `workspace` >= split_k*M*N*4 bytes (batch must be 1).
+ */
+typedef struct {
+  const void* a;
+  const void* w;
+  const float* bias;     /* [N] or NULL */
+  const float* addend;   /* per-row-group addend or NULL (ResBlock temb: unet.py:386-388) */
+  const void* residual;  /* same dtype as out, or NULL */
+  void* out;
+  void* workspace;
+  size_t workspace_bytes;
+  int64_t lda, ldr, ldc_m, ldc_n;
+  int64_t stride_a, stride_w, stride_c, stride_r; /* per batch, elements */
+  int64_t add_ld;        /* row stride of addend (0 = one row for all groups) */
+  int32_t M, N, K, batch;
+  int32_t add_rows;      /* rows of out per addend row (OH*OW) */
+  int32_t conv, B, H, W, Cin, OH, OW, stride, upsample;
+  int32_t act;
+  int32_t dtype;         /* of a, w */
+  int32_t out_dtype;     /* of out, residual */
+  int32_t split_k;       /* 0 = let the library choose */
+  int32_t tile;          /* 0 = auto; else force a tile config (tuning / tests) */
+  float alpha;
+} ldm_gemm_params;
+
+int ldm_gemm(const ldm_gemm_params* p, void* stream);
+/* bytes of workspace ldm_gemm may need for these params with split_k = 0 (auto) */
+size_t ldm_gemm_workspace_bytes(const ldm_gemm_params* p);
+
+/*
+ * Small direct 3x3 SAME convolution for tiny channel counts (Cin <= 8 or Cout <= 8):
+ * conv_in 4->C (unet.py:71, autoencoder.py:275) and conv_out C->4/3 (unet.py:116,
+ * autoencoder.py:289).  x [B][H][W][Cin] dtype in_dtype (pixel stride ldx), kernel
+ * HWIO float32, bias float32, out dtype out_dtype (pixel stride ldo).
+ */
+int ldm_conv3x3_small(const void* x, int64_t ldx, int in_dtype, const float* kernel_hwio,
+                      const float* bias, void* out, int64_t ldo, int out_dtype,
+                      int B, int H, int W, int Cin, int Cout, void* stream);
+
+/*
+ * GroupNormalization over NHWC (Keras semantics: biased variance over (H,W,C/G)),
+ * optionally followed by SiLU.  Two launches:
+ *   ldm_groupnorm_partial : per (b, chunk, g) sums  -> partial[B][nchunks][G][2] float
+ *   ldm_groupnorm_apply   : finalises mean/rstd, writes (x-mu)*rstd*gamma+beta [silu]
+ * nchunks is chosen by the caller (ldm_groupnorm_nchunks gives the library's choice).
+ * Replaces GroupNormalization(+tf.nn.silu): unet.py:115,137,354,374,377,383,390;
+ * autoencoder.py:31,33,68,237,288.
+ */
+int ldm_groupnorm_nchunks(int B, int HW, int C);
+int ldm_groupnorm_partial(const void* x, int64_t ldx, float* partial, int B, int HW, int C,
+                          int groups, int nchunks, int dtype, void* stream);
+int ldm_groupnorm_apply(const void* x, int64_t ldx, const float* partial, const float* gamma,
+                        const float* beta, void* out, int64_t ldo, int B, int HW, int C,
+                        int groups, int nchunks, float eps, int silu, int dtype, void* stream);
+
+/* LayerNormalization over the last axis (unet.py:304-306; transformer.py:165,170,209). */
+int ldm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out,
+                  int64_t ldo, int rows, int C, float eps, int dtype, void* stream);
+
+/* Row softmax of a [rows][cols] matrix after scaling by `scale` (autoencoder.py:86-90:
+ * einsum * C**-0.5 then softmax).  out may alias x when the dtypes are equal. */
+int ldm_softmax_rows(const void* x, int64_t ldx, int in_dtype, void* out, int64_t ldo,
+                     int out_dtype, int rows, int cols, float scale, void* stream);
+
+/*
+ * Fused multi-head attention, logits never materialised:
+ *   out[b][q][h][:] = softmax_c( scale * q[b][q][h][:] . k[b][c][h][:] ) @ v[b][c][h][:]
+ * q: [batch][Tq] rows of heads*Sp elements (row stride ldq), k likewise [batch][Tk];
+ * vt: V transposed per head: [batch][heads][Sp][ldvt] with ldvt >= Tk keys contiguous;
+ * out: [batch][Tq] rows of heads*Sp (row stride ldo).  Sp = head size padded to a
+ * multiple of 32 with zeros (the padding lives in the re-laid-out projection weights).
+ * Replaces unet.py:280-287 and transformer.py:107-116 (scale applied AFTER q.k^T).
+ */
+int ldm_attention(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                  int64_t k_bs, const void* vt, int64_t ldvt, int64_t vt_bs, void* out,
+                  int64_t ldo, int64_t o_bs, int batch, int heads, int Tq, int Tk, int Sp,
+                  float scale, int dtype, void* stream);
+
+/* Sinusoidal timestep embedding, cos first (unet.py:401-422): out[r][0:half]=cos(t*f),
+ * out[r][half:]=sin(t*f), f_k = exp(-ln(10000)*k/half), float32.  t is read from
+ * steps[*index] when `index` != NULL (device-resident DDIM index, graph replay) else
+ * from t_rows[r]. */
+int ldm_time_embedding(const int32_t* t_rows, const int32_t* steps, const int32_t* index,
+                       float* out, int rows, int channels, void* stream);
+
+/* y[r][n] = act_out( sum_k act_in(x[r][k]) * Wt[n][k] + bias[n] ), all float32 except Wt
+ * (dtype).  Skinny (rows <= 64) Dense used for the timestep MLP and the 22 ResBlock
+ * temb projections (unet.py:72-73,127,386).  act_*: LDM_ACT_NONE / LDM_ACT_SILU. */
+int ldm_gemv(const float* x, int64_t ldx, const void* wt, const float* bias, float* y,
+             int64_t ldy, int rows, int N, int K, int act_in, int act_out, int dtype,
+             void* stream);
+
+/*
+ * Classifier-free guidance + DDIM update, float32 (model_runners.py:451-468):
+ *   eps = eps_u + s*(eps_c - eps_u); x0 = c1*xt - c2*eps; mean = sqrt(a_prev)*x0
+ *   + sqrt(1 - a_prev - sigma^2)*eps; xt' = mean + noise*sigma.
+ * eps_all [2B][n] (uncond rows first), xt/xt_out/noise [B][n] (noise may be NULL when
+ * sigma = 0).  coef = device table [N_steps][4] of float32 (c1, c2, a_prev, sigma)
+ * gathered at *index (the `_extract` cast-then-gather, :41-44).  If `dec_index` != 0
+ * the kernel decrements *index afterwards (device-side loop counter for graph replay).
+ * x_unet_out (optional, dtype x_dtype) receives concat([xt', xt']) for the next step
+ * (:452) so the next U-Net call reads it directly.
+ */
+int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const float* noise, float* xt_out,
+                        void* x_unet_out, int x_dtype, const float* coef, int32_t* index,
+                        int dec_index, float guidance_scale, int clip_denoised, int B,
+                        int64_t n_per_sample, void* stream);
+
+/* decode_first_stage prologue (model_runners.py:426 + autoencoder.py:362,434):
+ * out = Dense_{C->C}(latents / scale_factor), C <= 8; float32 in, out_dtype out. */
+int ldm_post_quant(const float* latents, float scale_factor, const float* kernel_io,
+                   const float* bias, void* out, int out_dtype, int64_t pixels, int C,
+                   void* stream);
+
+/* Nearest-codebook lookup (quantize.py:57-78): for each row z of [rows][C] (C <= 8):
+ * idx = argmin_e |z|^2+|e|^2-2 z.e over codebook [V][C]; out = z + (e[idx]-z);
+ * indices (int64) optional. */
+int ldm_vq_nearest(const float* z, const float* codebook, float* out, int64_t* indices,
+                   int64_t rows, int V, int C, void* stream);
+
+/* tok_emb[ids] + pos_emb[0..T-1] (transformer.py:261-268); ids int64 [rows*T]. */
+int ldm_embedding(const int64_t* ids, const float* tok_emb, const float* pos_emb, void* out,
+                  int rows, int T, int D, int vocab, int out_dtype, void* stream);
+
+/* tensor_to_image (run_ldm_sampler.py:18-25): per image (x-min)/(max-min)*255 -> uint8
+ * (truncation).  scratch: 128 floats per image. */
+int ldm_minmax_u8(const void* x, int in_dtype, uint8_t* out, float* scratch, int B,
+                  int64_t n_per_image, void* stream);
+
+/* dtype conversion / strided copy of [rows][cols] (cols contiguous). */
+int ldm_cast(const void* x, int64_t ldx, int in_dtype, void* out, int64_t ldo, int out_dtype,
+             int64_t rows, int cols, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDM_HIP_H */

@@ -1,0 +1,274 @@
+// Fused multi-head attention (flash style) on MFMA for gfx950.
+//
+// Transposed formulation so that softmax state is lane-local:
+//   S^T = K . Q^T   (A operand = K tile rows (keys), B operand = Q (lane = query))
+//   O^T = V^T . P^T (A operand = V^T rows (head dims), B operand = P = the S^T
+//                    accumulator itself, repacked in registers -- no LDS trip)
+// A 32x32 MFMA accumulator holds its COLUMN on the lane, so lane l owns query
+// (l & 31): its running max / sum and the rescale of its O^T column are plain
+// per-lane scalars; the only cross-lane step is one exchange with lane l^32.
+// For bf16 the rows of the K tile are read in the order kappa(i) = i with bits
+// 2 and 3 swapped, which makes the accumulator's register order the natural key
+// order of the following P.V MFMA (16-byte V^T fragments, no permutes).
+//
+// One workgroup = 4 waves = 128 queries of one (batch, head); K and V^T tiles of
+// KT keys are staged global -> registers -> LDS with the next tile's loads in
+// flight during the current tile's MFMAs.  Logits are never written to memory.
+#include "common.h"
+
+namespace {
+
+struct AttnArgs {
+  const char* q; const char* k; const char* vt; char* out;
+  int64_t ldq, q_bs, ldk, k_bs, ldvt, vt_bs, ldo, o_bs;
+  int heads, Tq, Tk;
+  float scale;
+};
+
+__device__ __forceinline__ void mma32a(f32x16& acc, const u32x4& a, const u32x4& b, bf16_t) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32a(f32x16& acc, const u32x4& a, const u32x4& b, float) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc,
+                                               0, 0, 0);
+}
+
+template <typename T> struct AttnTraits;
+template <> struct AttnTraits<bf16_t> {
+  static constexpr int KT = 64;   // keys per LDS tile
+  static constexpr int NPC = 2;   // P chunks (k-steps) per 32-key sub-tile
+  __device__ static __forceinline__ int kappa(int i) {  // swap bits 2 and 3
+    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
+  }
+  // P chunk pc of a sub-tile: registers 8pc..8pc+7 -> 8 bf16
+  __device__ static __forceinline__ u32x4 pchunk(const f32x16& s, int pc) {
+    u32x4 c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = pack_bf2(s[8 * pc + 2 * e], s[8 * pc + 2 * e + 1]);
+    return c;
+  }
+};
+template <> struct AttnTraits<float> {
+  static constexpr int KT = 32;
+  static constexpr int NPC = 4;
+  __device__ static __forceinline__ int kappa(int i) { return i; }
+  __device__ static __forceinline__ u32x4 pchunk(const f32x16& s, int pc) {
+    u32x4 c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = __float_as_uint(s[4 * pc + e]);
+    return c;
+  }
+};
+
+template <typename T, int SP>
+__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+  using TR = AttnTraits<T>;
+  constexpr int EPC = Elem<T>::kPerChunk;
+  constexpr int KT = TR::KT, NPC = TR::NPC;
+  constexpr int NSUB = KT / 32;
+  constexpr int DCH = SP / EPC;                 // 16-byte chunks per K row
+  constexpr int NKG = SP * (int)sizeof(T) / 32; // 32-byte k groups over the head dim
+  constexpr int ND = SP / 32;                   // O^T tiles
+  constexpr int KRS = SP * (int)sizeof(T) + 16; // padded LDS row strides (odd * 16 B)
+  constexpr int VRS = KT * (int)sizeof(T) + 16;
+  constexpr int CK = (KT * DCH + 255) / 256;
+  constexpr int CV = (SP * 8 + 255) / 256;
+
+  __shared__ __attribute__((aligned(16))) char smem[KT * KRS + SP * VRS];
+  char* sK = smem;
+  char* sV = smem + KT * KRS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  const T* Q = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)head * SP;
+  const T* Kp = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)head * SP;
+  const T* Vt = (const T*)p.vt + (int64_t)b * p.vt_bs + (int64_t)head * SP * p.ldvt;
+
+  // Q fragments: B operand, lane = query
+  u32x4 qf[NKG];
+  {
+    const int qi = min(q0 + lr, p.Tq - 1);
+    const T* qr = Q + (int64_t)qi * p.ldq;
+#pragma unroll
+    for (int g = 0; g < NKG; ++g) qf[g] = *(const u32x4*)(qr + (2 * g + lh) * EPC);
+  }
+
+  f32x16 o[ND];
+#pragma unroll
+  for (int d = 0; d < ND; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+
+  u32x4 rk[CK], rv[CV];
+  auto load_tile = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < CK; ++i) {
+      const int id = tid + i * 256;
+      const int key = id / DCH, dc = id - key * DCH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (id < KT * DCH && kt0 + key < p.Tk)
+        v = *(const u32x4*)(Kp + (int64_t)(kt0 + key) * p.ldk + dc * EPC);
+      rk[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < CV; ++i) {
+      const int id = tid + i * 256;
+      const int dim = id >> 3, kc = id & 7;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (id < SP * 8 && kt0 + kc * EPC < p.ldvt)
+        v = *(const u32x4*)(Vt + (int64_t)dim * p.ldvt + kt0 + kc * EPC);
+      rv[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < CK; ++i) {
+      const int id = tid + i * 256;
+      const int key = id / DCH, dc = id - key * DCH;
+      if (id < KT * DCH) *(u32x4*)(sK + key * KRS + dc * 16) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CV; ++i) {
+      const int id = tid + i * 256;
+      const int dim = id >> 3, kc = id & 7;
+      if (id < SP * 8) *(u32x4*)(sV + dim * VRS + kc * 16) = rv[i];
+    }
+  };
+
+  const int krow = TR::kappa(lr);
+  const int ntiles = (p.Tk + KT - 1) / KT;
+  load_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int kt0 = t * KT;
+    __syncthreads();
+    store_tile();
+    __syncthreads();
+    if (t + 1 < ntiles) load_tile(kt0 + KT);
+
+    // ---- S^T = K . Q^T ---------------------------------------------------------
+    f32x16 s[NSUB];
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+      const char* kr = sK + (j * 32 + krow) * KRS + lh * 16;
+#pragma unroll
+      for (int g = 0; g < NKG; ++g) {
+        const u32x4 kf = *(const u32x4*)(kr + g * 32);
+        mma32a(s[j], kf, qf[g], T());
+      }
+    }
+    // ---- online softmax (per lane = per query) ------------------------------------
+    float mt = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + j * 32 + TR::kappa((r & 3) + 8 * (r >> 2) + 4 * lh);
+        const float v = key < p.Tk ? s[j][r] * p.scale : -INFINITY;
+        s[j][r] = v;
+        mt = fmaxf(mt, v);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float ls = 0.f;
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float e = __expf(s[j][r] - m_new);
+        s[j][r] = e;
+        ls += e;
+      }
+    l_run = l_run * alpha + ls;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    // ---- O^T += V^T . P^T -------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+      for (int pc = 0; pc < NPC; ++pc) {
+        const u32x4 pf = TR::pchunk(s[j], pc);
+        const int coff = (j * 2 * NPC + 2 * pc + lh) * 16;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) {
+          const u32x4 vf = *(const u32x4*)(sV + (d * 32 + lr) * VRS + coff);
+          mma32a(o[d], vf, pf, T());
+        }
+      }
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qi = q0 + lr;
+  if (qi < p.Tq) {
+    T* orow = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)head * SP;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dim = d * 32 + 8 * r4 + 4 * lh;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[d][r4 * 4 + e] * inv;
+        if constexpr (sizeof(T) == 2) {
+          u32x2 pk; pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
+          *(u32x2*)(orow + dim) = pk;
+        } else {
+          f32x4 pk = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)(orow + dim) = pk;
+        }
+      }
+  }
+}
+
+template <typename T>
+int launch_attn(const AttnArgs& a, int Sp, dim3 grid, hipStream_t s) {
+  switch (Sp) {
+    case 32: hipLaunchKernelGGL((attn_kernel<T, 32>), grid, dim3(256), 0, s, a); break;
+    case 64: hipLaunchKernelGGL((attn_kernel<T, 64>), grid, dim3(256), 0, s, a); break;
+    case 96: hipLaunchKernelGGL((attn_kernel<T, 96>), grid, dim3(256), 0, s, a); break;
+    case 160: hipLaunchKernelGGL((attn_kernel<T, 160>), grid, dim3(256), 0, s, a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ldm_attention(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                             int64_t k_bs, const void* vt, int64_t ldvt, int64_t vt_bs, void* out,
+                             int64_t ldo, int64_t o_bs, int batch, int heads, int Tq, int Tk, int Sp,
+                             float scale, int dtype, void* stream) {
+  LDM_CHECK_ARG(q && k && vt && out, "ldm_attention: null pointer");
+  LDM_CHECK_ARG(dtype == LDM_F32 || dtype == LDM_BF16, "ldm_attention: bad dtype");
+  LDM_CHECK_ARG(batch > 0 && heads > 0 && Tq > 0 && Tk > 0, "ldm_attention: bad dims");
+  LDM_CHECK_ARG(batch < 65536 && heads < 65536, "ldm_attention: batch/heads too large");
+  const int epc = dtype == LDM_BF16 ? 8 : 4;
+  LDM_CHECK_ARG(ldq % epc == 0 && ldk % epc == 0 && ldvt % epc == 0 && ldo % epc == 0 &&
+                    q_bs % epc == 0 && k_bs % epc == 0 && vt_bs % epc == 0 && o_bs % epc == 0,
+                "ldm_attention: strides must be multiples of %d elements", epc);
+  LDM_CHECK_ARG(ldvt >= Tk, "ldm_attention: ldvt=%lld < Tk=%d", (long long)ldvt, Tk);
+  LDM_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0, "ldm_attention: pointers must be 16-byte aligned");
+  AttnArgs a;
+  a.q = (const char*)q; a.k = (const char*)k; a.vt = (const char*)vt; a.out = (char*)out;
+  a.ldq = ldq; a.q_bs = q_bs; a.ldk = ldk; a.k_bs = k_bs; a.ldvt = ldvt; a.vt_bs = vt_bs;
+  a.ldo = ldo; a.o_bs = o_bs; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.scale = scale;
+  dim3 grid((Tq + 127) / 128, heads, batch);
+  hipStream_t s = (hipStream_t)stream;
+  int r = dtype == LDM_BF16 ? launch_attn<bf16_t>(a, Sp, grid, s) : launch_attn<float>(a, Sp, grid, s);
+  LDM_CHECK_ARG(r == 0, "ldm_attention: unsupported padded head size Sp=%d (32/64/96/160)", Sp);
+  return ldm_launch_status("ldm_attention");
+}

@@ -1,0 +1,107 @@
+// Shared device/host helpers for libldm_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/ldm_hip.h"
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- error plumbing --------------------------------------------------------
+void ldm_set_error(const char* fmt, ...);
+#define LDM_CHECK_ARG(cond, ...)     \
+  do {                               \
+    if (!(cond)) {                   \
+      ldm_set_error(__VA_ARGS__);    \
+      return LDM_ERR_ARG;            \
+    }                                \
+  } while (0)
+
+static inline int ldm_launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    ldm_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+    return LDM_ERR_LAUNCH;
+  }
+  return LDM_OK;
+}
+
+// ---- scalar conversions ----------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int kPerChunk = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int kPerChunk = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// unpack one 16-byte chunk into floats
+__device__ __forceinline__ void chunk_to_f32(const u32x4& c, float (&f)[4], float) {
+  f[0] = __uint_as_float(c[0]); f[1] = __uint_as_float(c[1]);
+  f[2] = __uint_as_float(c[2]); f[3] = __uint_as_float(c[3]);
+}
+__device__ __forceinline__ void chunk_to_f32(const u32x4& c, float (&f)[8], bf16_t) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(c[i] << 16);
+    f[2 * i + 1] = __uint_as_float(c[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ u32x4 f32_to_chunk(const float (&f)[4], float) {
+  u32x4 c;
+  c[0] = __float_as_uint(f[0]); c[1] = __float_as_uint(f[1]);
+  c[2] = __float_as_uint(f[2]); c[3] = __float_as_uint(f[3]);
+  return c;
+}
+__device__ __forceinline__ u32x4 f32_to_chunk(const float (&f)[8], bf16_t) {
+  u32x4 c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+  return c;
+}
+
+// ---- math ------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---- wave reductions (wave = 64) ------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}

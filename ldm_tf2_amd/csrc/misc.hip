@@ -1,0 +1,514 @@
+// Small / HBM-bound kernels of the sampling path: tiny-channel 3x3 convs, timestep
+// embedding + skinny Dense, CFG + DDIM update, first-stage prologue, VQ lookup,
+// token embedding, per-image min-max -> uint8, casts.
+#include "common.h"
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p);
+template <> __device__ __forceinline__ float ldf<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ---- conv_in: Cin <= 8, any Cout.  thread = (pixel, 4 consecutive couts) -------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void conv_small_in_kernel(const TI* __restrict__ x, int64_t ldx,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            TO* __restrict__ out, int64_t ldo, int B,
+                                                            int H, int W, int Cin, int Cout) {
+  const int cq = Cout >> 2;
+  const int64_t total = (int64_t)B * H * W * cq;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(idx % cq) * 4;
+    const int64_t pix = idx / cq;
+    const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    float acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = bias ? bias[c4 + e] : 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy + kh - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = ox + kw - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const TI* xp = x + ((int64_t)(b * H + iy) * W + ix) * ldx;
+        const float* wp = w + (int64_t)((kh * 3 + kw) * Cin) * Cout + c4;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float xv = ldf<TI>(xp + ci);
+          const f32x4 wv = *(const f32x4*)(wp + (int64_t)ci * Cout);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] += xv * wv[e];
+        }
+      }
+    }
+    TO* op = out + pix * ldo + c4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) stf<TO>(op + e, acc[e]);
+  }
+}
+
+// ---- conv_out: Cout <= 4, Cin multiple of 16-byte chunks.  One wave = 8 pixels,
+// 8 lanes split the 9*Cin reduction of one pixel; weights [9*Cin][Cout] f32 in LDS.
+template <typename TI, typename TO, int COUT>
+__global__ __launch_bounds__(256) void conv_small_out_kernel(const TI* __restrict__ x, int64_t ldx,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             TO* __restrict__ out, int64_t ldo,
+                                                             int B, int H, int W, int Cin) {
+  constexpr int EPC = Elem<TI>::kPerChunk;
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [9*Cin][COUT]
+  const int nw = 9 * Cin * COUT;
+  for (int i = threadIdx.x; i < nw; i += 256) sw[i] = w[i];
+  __syncthreads();
+  const int sub = threadIdx.x & 7;
+  const int64_t npix = (int64_t)B * H * W;
+  const int nvec = Cin / EPC;
+  for (int64_t pix = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix;
+       pix += (int64_t)gridDim.x * 32) {
+    const int ox = (int)(pix % W), oy = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    float acc[COUT];
+#pragma unroll
+    for (int e = 0; e < COUT; ++e) acc[e] = 0.f;
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy + kh - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        const int ix = ox + kw - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const TI* xp = x + ((int64_t)(b * H + iy) * W + ix) * ldx;
+        const float* wp = sw + (kh * 3 + kw) * Cin * COUT;
+        for (int v = sub; v < nvec; v += 8) {
+          const u32x4 c = *(const u32x4*)(xp + v * EPC);
+          float f[EPC];
+          chunk_to_f32(c, f, TI());
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            const float* wr = wp + (v * EPC + e) * COUT;
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] += f[e] * wr[co];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+      float v = acc[co];
+      v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+      acc[co] = v;
+    }
+    if (sub == 0) {
+      TO* op = out + pix * ldo;
+#pragma unroll
+      for (int co = 0; co < COUT; ++co) stf<TO>(op + co, acc[co] + (bias ? bias[co] : 0.f));
+    }
+  }
+}
+
+// ---- timestep embedding -------------------------------------------------------
+__global__ void time_embedding_kernel(const int32_t* __restrict__ t_rows,
+                                      const int32_t* __restrict__ steps,
+                                      const int32_t* __restrict__ index, float* __restrict__ out,
+                                      int rows, int channels) {
+  const int half = channels / 2;
+  const int total = rows * half;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / half, k = i - r * half;
+    const int t = index ? steps[*index] : t_rows[r];
+    // freqs = exp(-ln(10000) * k / half) in float32 (unet.py:413-416)
+    const float f = expf(-logf(10000.0f) * (float)k / (float)half);
+    const float a = (float)t * f;
+    out[(int64_t)r * channels + k] = cosf(a);
+    out[(int64_t)r * channels + half + k] = sinf(a);
+    if ((channels & 1) && k == 0) out[(int64_t)r * channels + channels - 1] = 0.f;
+  }
+}
+
+// ---- skinny Dense: one wave per output column n, all rows at once (rows <= 64) ---
+template <typename T, int RT>
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, int64_t ldx,
+                                                   const T* __restrict__ wt,
+                                                   const float* __restrict__ bias,
+                                                   float* __restrict__ y, int64_t ldy, int rows, int N,
+                                                   int K, int act_in, int act_out) {
+  constexpr int EPC = Elem<T>::kPerChunk;
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int r0 = blockIdx.y * RT;
+  float acc[RT];
+#pragma unroll
+  for (int r = 0; r < RT; ++r) acc[r] = 0.f;
+  const T* wr = wt + (int64_t)n * K;
+  for (int k = lane * EPC; k < K; k += 64 * EPC) {
+    const u32x4 c = *(const u32x4*)(wr + k);
+    float wv[EPC];
+    chunk_to_f32(c, wv, T());
+#pragma unroll
+    for (int r = 0; r < RT; ++r) {
+      if (r0 + r < rows) {
+        const float* xr = x + (int64_t)(r0 + r) * ldx + k;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) {
+          float xv = xr[e];
+          if (act_in == LDM_ACT_SILU) xv = silu_f(xv);
+          acc[r] += xv * wv[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const float s = wave_sum(acc[r]);
+    if (lane == 0 && r0 + r < rows) {
+      float v = s + (bias ? bias[n] : 0.f);
+      if (act_out == LDM_ACT_SILU) v = silu_f(v);
+      y[(int64_t)(r0 + r) * ldy + n] = v;
+    }
+  }
+}
+
+// ---- CFG + DDIM update --------------------------------------------------------------
+template <typename TX>
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__ eps_all,
+                                                       const float* __restrict__ xt,
+                                                       const float* __restrict__ noise,
+                                                       float* __restrict__ xt_out,
+                                                       TX* __restrict__ x_unet, const float* coef,
+                                                       int32_t* index, int dec_index, float gs,
+                                                       int clip, int B, int64_t n) {
+  const int idx = *index;
+  const float c1 = coef[idx * 4 + 0], c2 = coef[idx * 4 + 1];
+  const float a_prev = coef[idx * 4 + 2], sigma = coef[idx * 4 + 3];
+  const float sa = sqrtf(a_prev);
+  const float sb = sqrtf(1.0f - a_prev - sigma * sigma);
+  const int64_t total = (int64_t)B * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const float eu = eps_all[i], ec = eps_all[total + i];
+    const float eps = eu + gs * (ec - eu);
+    const float x = xt[i];
+    float x0 = c1 * x - c2 * eps;
+    if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+    const float mean = sa * x0 + sb * eps;
+    const float o = mean + (noise ? noise[i] : 0.f) * sigma;
+    xt_out[i] = o;
+    if (x_unet) { stf<TX>(x_unet + i, o); stf<TX>(x_unet + total + i, o); }
+  }
+}
+// decrement happens in its own 1-thread kernel AFTER the update so that every block
+// of the update kernel has read *index first
+__global__ void dec_index_kernel(int32_t* index) { *index = *index - 1; }
+
+// ---- post_quant: out = Dense(latents / sf) ----------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void post_quant_kernel(const float* __restrict__ z, float sf,
+                                                         const float* __restrict__ kio,
+                                                         const float* __restrict__ bias,
+                                                         TO* __restrict__ out, int64_t pixels, int C) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < pixels; p += (int64_t)gridDim.x * 256) {
+    float zi[8];
+    for (int i = 0; i < C; ++i) zi[i] = z[p * C + i] / sf;
+    for (int o = 0; o < C; ++o) {
+      float a = 0.f;
+      for (int i = 0; i < C; ++i) a += zi[i] * kio[i * C + o];
+      stf<TO>(out + p * C + o, a + (bias ? bias[o] : 0.f));
+    }
+  }
+}
+
+// ---- VQ nearest: one wave per row, lanes stride the codebook ------------------------
+__global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z,
+                                                         const float* __restrict__ cb,
+                                                         float* __restrict__ out,
+                                                         int64_t* __restrict__ indices, int64_t rows,
+                                                         int V, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float zi[8];
+  float zz = 0.f;
+  for (int i = 0; i < C; ++i) { zi[i] = z[row * C + i]; zz += zi[i] * zi[i]; }
+  float best = INFINITY;
+  int bidx = 0x7fffffff;
+  for (int v = lane; v < V; v += 64) {
+    float ee = 0.f, ze = 0.f;
+    for (int i = 0; i < C; ++i) { const float e = cb[(int64_t)v * C + i]; ee += e * e; ze += zi[i] * e; }
+    const float d = zz + ee - 2.0f * ze;   // quantize.py:66-70
+    if (d < best) { best = d; bidx = v; }
+  }
+  // argmin with lowest-index tie break (tf.argmin returns the first minimum)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bidx, o, 64);
+    if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  }
+  if (lane < C) {
+    const float zv = z[row * C + lane];
+    const float q = cb[(int64_t)bidx * C + lane];
+    out[row * C + lane] = zv + (q - zv);   // quantize.py:87 straight-through form
+  }
+  if (lane == 0 && indices) indices[row] = bidx;
+}
+
+// ---- token + positional embedding ---------------------------------------------------
+template <typename TO>
+__global__ __launch_bounds__(256) void embedding_kernel(const int64_t* __restrict__ ids,
+                                                        const float* __restrict__ tok,
+                                                        const float* __restrict__ pos,
+                                                        TO* __restrict__ out, int rows, int T, int D,
+                                                        int vocab) {
+  const int64_t total = (int64_t)rows * T * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int d = (int)(i % D);
+    const int64_t rt = i / D;
+    const int t = (int)(rt % T);
+    int64_t id = ids[rt];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    stf<TO>(out + i, tok[id * D + d] + pos[(int64_t)t * D + d]);
+  }
+}
+
+// ---- min-max -> uint8 ------------------------------------------------------------------
+template <typename TI>
+__global__ __launch_bounds__(256) void minmax_kernel(const TI* __restrict__ x, float* scratch,
+                                                     int64_t n) {
+  // grid (nblk, B); scratch[b][nblk][2]
+  __shared__ float smin[4], smax[4];
+  const int b = blockIdx.y;
+  const TI* xb = x + (int64_t)b * n;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float v = ldf<TI>(xb + i);
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+  mn = wave_min(mn); mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = scratch + ((int64_t)b * gridDim.x + blockIdx.x) * 2;
+    o[0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    o[1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+  }
+}
+template <typename TI>
+__global__ __launch_bounds__(256) void to_u8_kernel(const TI* __restrict__ x, const float* scratch,
+                                                    int nblk, uint8_t* __restrict__ out, int64_t n) {
+  const int b = blockIdx.y;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = 0; i < nblk; ++i) {
+    mn = fminf(mn, scratch[((int64_t)b * nblk + i) * 2]);
+    mx = fmaxf(mx, scratch[((int64_t)b * nblk + i) * 2 + 1]);
+  }
+  const float range = mx - mn;
+  const TI* xb = x + (int64_t)b * n;
+  uint8_t* ob = out + (int64_t)b * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float v = (ldf<TI>(xb + i) - mn) / range;   // run_ldm_sampler.py:21-22
+    v *= 255.0f;                                  // :23
+    ob[i] = (uint8_t)v;                           // :24 astype(uint8): truncation
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, int64_t ldx,
+                                                   TO* __restrict__ out, int64_t ldo, int64_t rows,
+                                                   int cols) {
+  const int64_t total = rows * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / cols;
+    const int c = (int)(i - r * cols);
+    stf<TO>(out + r * ldo + c, ldf<TI>(x + r * ldx + c));
+  }
+}
+
+inline int grid_for(int64_t total, int per_block = 256, int cap = 4096) {
+  int64_t g = (total + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+constexpr int kMinmaxBlocks = 64;
+
+}  // namespace
+
+#define DT_OK(d) ((d) == LDM_F32 || (d) == LDM_BF16)
+
+extern "C" int ldm_conv3x3_small(const void* x, int64_t ldx, int in_dtype, const float* kernel_hwio,
+                                 const float* bias, void* out, int64_t ldo, int out_dtype, int B,
+                                 int H, int W, int Cin, int Cout, void* stream) {
+  LDM_CHECK_ARG(x && kernel_hwio && out, "ldm_conv3x3_small: null pointer");
+  LDM_CHECK_ARG(DT_OK(in_dtype) && DT_OK(out_dtype), "ldm_conv3x3_small: bad dtype");
+  LDM_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ldm_conv3x3_small: bad dims");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t npix = (int64_t)B * H * W;
+  if (Cin <= 8) {
+    LDM_CHECK_ARG(Cout % 4 == 0, "ldm_conv3x3_small: Cout must be a multiple of 4 when Cin <= 8");
+    dim3 g(grid_for(npix * (Cout / 4), 256, 8192));
+#define LAUNCH_IN(TI, TO)                                                                          \
+  hipLaunchKernelGGL((conv_small_in_kernel<TI, TO>), g, dim3(256), 0, s, (const TI*)x, ldx,        \
+                     kernel_hwio, bias, (TO*)out, ldo, B, H, W, Cin, Cout)
+    if (in_dtype == LDM_F32 && out_dtype == LDM_F32) LAUNCH_IN(float, float);
+    else if (in_dtype == LDM_F32) LAUNCH_IN(float, bf16_t);
+    else if (out_dtype == LDM_F32) LAUNCH_IN(bf16_t, float);
+    else LAUNCH_IN(bf16_t, bf16_t);
+#undef LAUNCH_IN
+    return ldm_launch_status("ldm_conv3x3_small(in)");
+  }
+  LDM_CHECK_ARG(Cout <= 4, "ldm_conv3x3_small: needs Cin <= 8 or Cout <= 4 (got %d -> %d)", Cin, Cout);
+  const int epc = in_dtype == LDM_BF16 ? 8 : 4;
+  LDM_CHECK_ARG(Cin % epc == 0 && ldx % epc == 0 && ((uintptr_t)x % 16) == 0,
+                "ldm_conv3x3_small: Cin/ldx/x alignment");
+  const size_t shm = (size_t)9 * Cin * Cout * sizeof(float);
+  LDM_CHECK_ARG(shm <= 64 * 1024, "ldm_conv3x3_small: Cin*Cout too large for LDS");
+  dim3 g(grid_for(npix, 32, 4096));
+#define LAUNCH_OUT(TI, TO, CO)                                                                     \
+  hipLaunchKernelGGL((conv_small_out_kernel<TI, TO, CO>), g, dim3(256), shm, s, (const TI*)x, ldx, \
+                     kernel_hwio, bias, (TO*)out, ldo, B, H, W, Cin)
+#define LAUNCH_OUT_T(TI, TO)                        \
+  switch (Cout) {                                   \
+    case 1: LAUNCH_OUT(TI, TO, 1); break;           \
+    case 2: LAUNCH_OUT(TI, TO, 2); break;           \
+    case 3: LAUNCH_OUT(TI, TO, 3); break;           \
+    default: LAUNCH_OUT(TI, TO, 4); break;          \
+  }
+  if (in_dtype == LDM_F32 && out_dtype == LDM_F32) { LAUNCH_OUT_T(float, float) }
+  else if (in_dtype == LDM_F32) { LAUNCH_OUT_T(float, bf16_t) }
+  else if (out_dtype == LDM_F32) { LAUNCH_OUT_T(bf16_t, float) }
+  else { LAUNCH_OUT_T(bf16_t, bf16_t) }
+#undef LAUNCH_OUT_T
+#undef LAUNCH_OUT
+  return ldm_launch_status("ldm_conv3x3_small(out)");
+}
+
+extern "C" int ldm_time_embedding(const int32_t* t_rows, const int32_t* steps, const int32_t* index,
+                                  float* out, int rows, int channels, void* stream) {
+  LDM_CHECK_ARG(out && rows > 0 && channels > 1, "ldm_time_embedding: bad args");
+  LDM_CHECK_ARG((index && steps) || t_rows, "ldm_time_embedding: need t_rows or (steps, index)");
+  hipLaunchKernelGGL(time_embedding_kernel, dim3(grid_for((int64_t)rows * (channels / 2))), dim3(256),
+                     0, (hipStream_t)stream, t_rows, steps, index, out, rows, channels);
+  return ldm_launch_status("ldm_time_embedding");
+}
+
+extern "C" int ldm_gemv(const float* x, int64_t ldx, const void* wt, const float* bias, float* y,
+                        int64_t ldy, int rows, int N, int K, int act_in, int act_out, int dtype,
+                        void* stream) {
+  LDM_CHECK_ARG(x && wt && y, "ldm_gemv: null pointer");
+  LDM_CHECK_ARG(DT_OK(dtype), "ldm_gemv: bad dtype");
+  const int epc = dtype == LDM_BF16 ? 8 : 4;
+  LDM_CHECK_ARG(rows > 0 && N > 0 && K > 0 && K % epc == 0 && ((uintptr_t)wt % 16) == 0,
+                "ldm_gemv: K=%d must be a multiple of %d", K, epc);
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int RT = 4;
+  dim3 g((N + 3) / 4, (rows + RT - 1) / RT);
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL((gemv_kernel<bf16_t, RT>), g, dim3(256), 0, s, x, ldx, (const bf16_t*)wt, bias,
+                       y, ldy, rows, N, K, act_in, act_out);
+  else
+    hipLaunchKernelGGL((gemv_kernel<float, RT>), g, dim3(256), 0, s, x, ldx, (const float*)wt, bias, y,
+                       ldy, rows, N, K, act_in, act_out);
+  return ldm_launch_status("ldm_gemv");
+}
+
+extern "C" int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const float* noise,
+                                   float* xt_out, void* x_unet_out, int x_dtype, const float* coef,
+                                   int32_t* index, int dec_index, float guidance_scale,
+                                   int clip_denoised, int B, int64_t n_per_sample, void* stream) {
+  LDM_CHECK_ARG(eps_all && xt && xt_out && coef && index, "ldm_cfg_ddim_update: null pointer");
+  LDM_CHECK_ARG(DT_OK(x_dtype) && B > 0 && n_per_sample > 0, "ldm_cfg_ddim_update: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(grid_for((int64_t)B * n_per_sample, 256, 1024));
+  if (x_dtype == LDM_BF16)
+    hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, g, dim3(256), 0, s, eps_all, xt, noise, xt_out,
+                       (bf16_t*)x_unet_out, coef, index, dec_index, guidance_scale, clip_denoised, B,
+                       n_per_sample);
+  else
+    hipLaunchKernelGGL(cfg_ddim_kernel<float>, g, dim3(256), 0, s, eps_all, xt, noise, xt_out,
+                       (float*)x_unet_out, coef, index, dec_index, guidance_scale, clip_denoised, B,
+                       n_per_sample);
+  int st = ldm_launch_status("ldm_cfg_ddim_update");
+  if (st != LDM_OK) return st;
+  if (dec_index) {
+    hipLaunchKernelGGL(dec_index_kernel, dim3(1), dim3(1), 0, s, index);
+    st = ldm_launch_status("ldm_cfg_ddim_update(dec)");
+  }
+  return st;
+}
+
+extern "C" int ldm_post_quant(const float* latents, float scale_factor, const float* kernel_io,
+                              const float* bias, void* out, int out_dtype, int64_t pixels, int C,
+                              void* stream) {
+  LDM_CHECK_ARG(latents && kernel_io && out && pixels > 0 && C > 0 && C <= 8 && DT_OK(out_dtype),
+                "ldm_post_quant: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(grid_for(pixels));
+  if (out_dtype == LDM_BF16)
+    hipLaunchKernelGGL(post_quant_kernel<bf16_t>, g, dim3(256), 0, s, latents, scale_factor, kernel_io,
+                       bias, (bf16_t*)out, pixels, C);
+  else
+    hipLaunchKernelGGL(post_quant_kernel<float>, g, dim3(256), 0, s, latents, scale_factor, kernel_io,
+                       bias, (float*)out, pixels, C);
+  return ldm_launch_status("ldm_post_quant");
+}
+
+extern "C" int ldm_vq_nearest(const float* z, const float* codebook, float* out, int64_t* indices,
+                              int64_t rows, int V, int C, void* stream) {
+  LDM_CHECK_ARG(z && codebook && out && rows > 0 && V > 0 && C > 0 && C <= 8, "ldm_vq_nearest: bad args");
+  LDM_CHECK_ARG((rows + 3) / 4 < (1ll << 31), "ldm_vq_nearest: too many rows");
+  hipLaunchKernelGGL(vq_nearest_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, z, codebook, out, indices, rows, V, C);
+  return ldm_launch_status("ldm_vq_nearest");
+}
+
+extern "C" int ldm_embedding(const int64_t* ids, const float* tok_emb, const float* pos_emb, void* out,
+                             int rows, int T, int D, int vocab, int out_dtype, void* stream) {
+  LDM_CHECK_ARG(ids && tok_emb && pos_emb && out && rows > 0 && T > 0 && D > 0 && vocab > 0 &&
+                    DT_OK(out_dtype), "ldm_embedding: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(grid_for((int64_t)rows * T * D));
+  if (out_dtype == LDM_BF16)
+    hipLaunchKernelGGL(embedding_kernel<bf16_t>, g, dim3(256), 0, s, ids, tok_emb, pos_emb,
+                       (bf16_t*)out, rows, T, D, vocab);
+  else
+    hipLaunchKernelGGL(embedding_kernel<float>, g, dim3(256), 0, s, ids, tok_emb, pos_emb, (float*)out,
+                       rows, T, D, vocab);
+  return ldm_launch_status("ldm_embedding");
+}
+
+extern "C" int ldm_minmax_u8(const void* x, int in_dtype, uint8_t* out, float* scratch, int B,
+                             int64_t n_per_image, void* stream) {
+  LDM_CHECK_ARG(x && out && scratch && B > 0 && n_per_image > 0 && DT_OK(in_dtype),
+                "ldm_minmax_u8: bad args (scratch needs %d floats per image)", 2 * kMinmaxBlocks);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g1(kMinmaxBlocks, B), g2(grid_for(n_per_image, 256, 256), B);
+  if (in_dtype == LDM_BF16) {
+    hipLaunchKernelGGL(minmax_kernel<bf16_t>, g1, dim3(256), 0, s, (const bf16_t*)x, scratch, n_per_image);
+    hipLaunchKernelGGL(to_u8_kernel<bf16_t>, g2, dim3(256), 0, s, (const bf16_t*)x, scratch,
+                       kMinmaxBlocks, out, n_per_image);
+  } else {
+    hipLaunchKernelGGL(minmax_kernel<float>, g1, dim3(256), 0, s, (const float*)x, scratch, n_per_image);
+    hipLaunchKernelGGL(to_u8_kernel<float>, g2, dim3(256), 0, s, (const float*)x, scratch,
+                       kMinmaxBlocks, out, n_per_image);
+  }
+  return ldm_launch_status("ldm_minmax_u8");
+}
+
+extern "C" int ldm_cast(const void* x, int64_t ldx, int in_dtype, void* out, int64_t ldo,
+                        int out_dtype, int64_t rows, int cols, void* stream) {
+  LDM_CHECK_ARG(x && out && rows > 0 && cols > 0 && DT_OK(in_dtype) && DT_OK(out_dtype),
+                "ldm_cast: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(grid_for(rows * cols));
+  if (in_dtype == LDM_F32 && out_dtype == LDM_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), g, dim3(256), 0, s, (const float*)x, ldx, (float*)out, ldo, rows, cols);
+  else if (in_dtype == LDM_F32)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), g, dim3(256), 0, s, (const float*)x, ldx, (bf16_t*)out, ldo, rows, cols);
+  else if (out_dtype == LDM_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), g, dim3(256), 0, s, (const bf16_t*)x, ldx, (float*)out, ldo, rows, cols);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, rows, cols);
+  return ldm_launch_status("ldm_cast");
+}

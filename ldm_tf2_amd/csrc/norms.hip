@@ -1,0 +1,315 @@
+// GroupNorm (+SiLU), LayerNorm, row softmax -- HBM-bound streaming kernels.
+// All loads/stores are 16 bytes per lane; statistics are float32.
+#include "common.h"
+
+namespace {
+
+// Column tiling shared by the two GroupNorm kernels: a 256-thread block covers
+// VT = min(nvec, 256) 16-byte channel vectors x P = 256/VT pixels at a time.
+struct GnGeom {
+  int nvec, VT, P;
+};
+__host__ __device__ inline GnGeom gn_geom(int C, int epc) {
+  GnGeom g;
+  g.nvec = C / epc;
+  g.VT = g.nvec < 256 ? g.nvec : 256;
+  g.P = 256 / g.VT;
+  return g;
+}
+
+// partial[b][chunk][g][2] = (sum x, sum x^2) over the chunk's pixels and group g
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int64_t ldx,
+                                                         float* __restrict__ partial, int HW, int C,
+                                                         int G, int nchunks) {
+  constexpr int EPC = Elem<T>::kPerChunk;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [2][P][C]
+  const GnGeom gg = gn_geom(C, EPC);
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int ppc = (HW + nchunks - 1) / nchunks;
+  const int p_begin = chunk * ppc, p_end = min(HW, p_begin + ppc);
+  const int pl = tid / gg.VT, vl = tid - pl * gg.VT;
+  const T* xb = x + (int64_t)b * HW * ldx;
+  float* s1 = sm;
+  float* s2 = sm + gg.P * C;
+  for (int v0 = 0; v0 < gg.nvec; v0 += gg.VT) {
+    const int v = v0 + vl;
+    float a1[EPC], a2[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
+    if (pl < gg.P && v < gg.nvec) {
+      for (int p = p_begin + pl; p < p_end; p += gg.P) {
+        const u32x4 c = *(const u32x4*)(xb + (int64_t)p * ldx + v * EPC);
+        float f[EPC];
+        chunk_to_f32(c, f, T());
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) { a1[e] += f[e]; a2[e] += f[e] * f[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        s1[pl * C + v * EPC + e] = a1[e];
+        s2[pl * C + v * EPC + e] = a2[e];
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c)
+      for (int q = 0; q < gg.P; ++q) { t1 += s1[q * C + c]; t2 += s2[q * C + c]; }
+    float* o = partial + (((int64_t)b * nchunks + chunk) * G + g) * 2;
+    o[0] = t1; o[1] = t2;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, int64_t ldx,
+                                                       const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta,
+                                                       T* __restrict__ out, int64_t ldo, int HW,
+                                                       int C, int G, int nchunks, int achunks,
+                                                       float eps, int do_silu) {
+  constexpr int EPC = Elem<T>::kPerChunk;
+  __shared__ float s_mean[64], s_rstd[64];
+  const GnGeom gg = gn_geom(C, EPC);
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float t1 = 0.f, t2 = 0.f;
+    for (int c = 0; c < nchunks; ++c) {
+      const float* o = partial + (((int64_t)b * nchunks + c) * G + g) * 2;
+      t1 += o[0]; t2 += o[1];
+    }
+    const float n = (float)HW * (float)cpg;
+    const float mean = t1 / n;
+    float var = t2 / n - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    s_mean[g] = mean;
+    s_rstd[g] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  const int ppc = (HW + achunks - 1) / achunks;
+  const int p_begin = chunk * ppc, p_end = min(HW, p_begin + ppc);
+  const int pl = tid / gg.VT, vl = tid - pl * gg.VT;
+  const T* xb = x + (int64_t)b * HW * ldx;
+  T* ob = out + (int64_t)b * HW * ldo;
+  for (int v0 = 0; v0 < gg.nvec; v0 += gg.VT) {
+    const int v = v0 + vl;
+    if (!(pl < gg.P && v < gg.nvec)) continue;
+    float mu[EPC], sc[EPC], sh[EPC];
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) {
+      const int c = v * EPC + e;
+      const int g = c / cpg;
+      mu[e] = s_mean[g];
+      sc[e] = s_rstd[g] * gamma[c];
+      sh[e] = beta[c];
+    }
+    for (int p = p_begin + pl; p < p_end; p += gg.P) {
+      const u32x4 cin = *(const u32x4*)(xb + (int64_t)p * ldx + v * EPC);
+      float f[EPC];
+      chunk_to_f32(cin, f, T());
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        float y = (f[e] - mu[e]) * sc[e] + sh[e];
+        f[e] = do_silu ? silu_f(y) : y;
+      }
+      *(u32x4*)(ob + (int64_t)p * ldo + v * EPC) = f32_to_chunk(f, T());
+    }
+  }
+}
+
+// one wave per row; the row lives in registers between the two passes
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        T* __restrict__ out, int64_t ldo, int rows,
+                                                        int C, float eps) {
+  constexpr int EPC = Elem<T>::kPerChunk;
+  constexpr int MAXV = 8;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = C / EPC;
+  const T* xr = x + (int64_t)row * ldx;
+  u32x4 buf[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nvec) {
+      buf[i] = *(const u32x4*)(xr + v * EPC);
+      float f[EPC];
+      chunk_to_f32(buf[i], f, T());
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) s += f[e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nvec) {
+      float f[EPC];
+      chunk_to_f32(buf[i], f, T());
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { const float d = f[e] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  T* orow = out + (int64_t)row * ldo;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < nvec) {
+      float f[EPC];
+      chunk_to_f32(buf[i], f, T());
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) {
+        const int c = v * EPC + e;
+        f[e] = (f[e] - mean) * rstd * gamma[c] + beta[c];
+      }
+      *(u32x4*)(orow + v * EPC) = f32_to_chunk(f, T());
+    }
+  }
+}
+
+// one block per row; out may alias x when TI == TO
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const TI* x, int64_t ldx, TO* out,
+                                                           int64_t ldo, int cols, float scale) {
+  __shared__ float red[4];
+  const TI* r = x + (int64_t)blockIdx.x * ldx;
+  TO* o = out + (int64_t)blockIdx.x * ldo;
+  const int tid = threadIdx.x;
+  float m = -INFINITY;
+  for (int c = tid; c < cols; c += 256) m = fmaxf(m, Elem<TI>::ld(r + c) * scale);
+  m = wave_max(m);
+  if ((tid & 63) == 0) red[tid >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int c = tid; c < cols; c += 256) s += __expf(Elem<TI>::ld(r + c) * scale - m);
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / s;
+  // a thread only ever rewrites the columns it alone reads, so aliasing is safe
+  // when sizeof(TI) == sizeof(TO); f32 -> bf16 must not alias.
+  for (int c = tid; c < cols; c += 256)
+    Elem<TO>::st(o + c, __expf(Elem<TI>::ld(r + c) * scale - m) * inv);
+}
+
+}  // namespace
+
+extern "C" int ldm_groupnorm_nchunks(int B, int HW, int C) {
+  (void)C;
+  int n = (1024 + B - 1) / B;
+  int cap = HW / 32;
+  if (cap < 1) cap = 1;
+  if (n > cap) n = cap;
+  if (n > 128) n = 128;
+  if (n < 1) n = 1;
+  return n;
+}
+
+static int gn_check(const char* who, const void* x, int64_t ldx, int B, int HW, int C, int groups,
+                    int nchunks, int dtype) {
+  LDM_CHECK_ARG(x, "%s: null x", who);
+  LDM_CHECK_ARG(dtype == LDM_F32 || dtype == LDM_BF16, "%s: bad dtype", who);
+  const int epc = dtype == LDM_BF16 ? 8 : 4;
+  LDM_CHECK_ARG(B > 0 && HW > 0 && C > 0 && groups > 0 && groups <= 64 && nchunks > 0,
+                "%s: bad dims", who);
+  LDM_CHECK_ARG(C % groups == 0 && C % epc == 0 && ldx % epc == 0 && ((uintptr_t)x % 16) == 0,
+                "%s: C=%d must divide by groups=%d and %d; ldx, x 16-byte aligned", who, C, groups, epc);
+  return LDM_OK;
+}
+
+extern "C" int ldm_groupnorm_partial(const void* x, int64_t ldx, float* partial, int B, int HW,
+                                     int C, int groups, int nchunks, int dtype, void* stream) {
+  int st = gn_check("ldm_groupnorm_partial", x, ldx, B, HW, C, groups, nchunks, dtype);
+  if (st) return st;
+  LDM_CHECK_ARG(partial, "ldm_groupnorm_partial: null partial");
+  const int epc = dtype == LDM_BF16 ? 8 : 4;
+  const GnGeom gg = gn_geom(C, epc);
+  const size_t shm = (size_t)2 * gg.P * C * sizeof(float);
+  LDM_CHECK_ARG(shm <= 64 * 1024, "ldm_groupnorm_partial: C=%d too large", C);
+  dim3 grid(nchunks, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), shm, s, (const bf16_t*)x, ldx,
+                       partial, HW, C, groups, nchunks);
+  else
+    hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), shm, s, (const float*)x, ldx,
+                       partial, HW, C, groups, nchunks);
+  return ldm_launch_status("ldm_groupnorm_partial");
+}
+
+extern "C" int ldm_groupnorm_apply(const void* x, int64_t ldx, const float* partial,
+                                   const float* gamma, const float* beta, void* out, int64_t ldo,
+                                   int B, int HW, int C, int groups, int nchunks, float eps, int silu,
+                                   int dtype, void* stream) {
+  int st = gn_check("ldm_groupnorm_apply", x, ldx, B, HW, C, groups, nchunks, dtype);
+  if (st) return st;
+  const int epc = dtype == LDM_BF16 ? 8 : 4;
+  LDM_CHECK_ARG(partial && gamma && beta && out, "ldm_groupnorm_apply: null pointer");
+  LDM_CHECK_ARG(ldo % epc == 0 && ((uintptr_t)out % 16) == 0, "ldm_groupnorm_apply: out alignment");
+  const int achunks = ldm_groupnorm_nchunks(B, HW, C);
+  dim3 grid(achunks, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, partial,
+                       gamma, beta, (bf16_t*)out, ldo, HW, C, groups, nchunks, achunks, eps, silu);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, partial,
+                       gamma, beta, (float*)out, ldo, HW, C, groups, nchunks, achunks, eps, silu);
+  return ldm_launch_status("ldm_groupnorm_apply");
+}
+
+extern "C" int ldm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta,
+                             void* out, int64_t ldo, int rows, int C, float eps, int dtype,
+                             void* stream) {
+  LDM_CHECK_ARG(x && gamma && beta && out, "ldm_layernorm: null pointer");
+  LDM_CHECK_ARG(dtype == LDM_F32 || dtype == LDM_BF16, "ldm_layernorm: bad dtype");
+  const int epc = dtype == LDM_BF16 ? 8 : 4;
+  LDM_CHECK_ARG(rows > 0 && C > 0 && C % epc == 0 && C / epc <= 8 * 64,
+                "ldm_layernorm: C=%d must be a multiple of %d and <= %d", C, epc, 512 * epc);
+  LDM_CHECK_ARG(ldx % epc == 0 && ldo % epc == 0 && ((uintptr_t)x % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0, "ldm_layernorm: alignment");
+  dim3 grid((rows + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == LDM_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, gamma,
+                       beta, (bf16_t*)out, ldo, rows, C, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, gamma,
+                       beta, (float*)out, ldo, rows, C, eps);
+  return ldm_launch_status("ldm_layernorm");
+}
+
+extern "C" int ldm_softmax_rows(const void* x, int64_t ldx, int in_dtype, void* out, int64_t ldo,
+                                int out_dtype, int rows, int cols, float scale, void* stream) {
+  LDM_CHECK_ARG(x && out && rows > 0 && cols > 0, "ldm_softmax_rows: bad args");
+  LDM_CHECK_ARG((in_dtype == LDM_F32 || in_dtype == LDM_BF16) &&
+                    (out_dtype == LDM_F32 || out_dtype == LDM_BF16), "ldm_softmax_rows: bad dtype");
+  LDM_CHECK_ARG(!(x == out && in_dtype != out_dtype), "ldm_softmax_rows: aliasing needs equal dtypes");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g(rows), b(256);
+  if (in_dtype == LDM_F32 && out_dtype == LDM_F32)
+    hipLaunchKernelGGL((softmax_rows_kernel<float, float>), g, b, 0, s, (const float*)x, ldx, (float*)out, ldo, cols, scale);
+  else if (in_dtype == LDM_F32)
+    hipLaunchKernelGGL((softmax_rows_kernel<float, bf16_t>), g, b, 0, s, (const float*)x, ldx, (bf16_t*)out, ldo, cols, scale);
+  else if (out_dtype == LDM_F32)
+    hipLaunchKernelGGL((softmax_rows_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)x, ldx, (float*)out, ldo, cols, scale);
+  else
+    hipLaunchKernelGGL((softmax_rows_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)x, ldx, (bf16_t*)out, ldo, cols, scale);
+  return ldm_launch_status("ldm_softmax_rows");
+}

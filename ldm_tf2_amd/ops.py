@@ -1,0 +1,306 @@
+"""Thin tensor-level wrappers over the C ABI (include/ldm_hip.h).
+
+torch is used here only as the device-memory container and stream provider:
+every function turns tensors into (pointer, stride, size) arguments and enqueues
+hand-written HIP kernels from libldm_hip.so on torch's current stream.  Nothing
+in this module computes with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_SILU, BF16, F32, GemmParams, check, lib
+
+__all__ = [
+    "ACT_NONE", "ACT_GELU", "ACT_GEGLU", "ACT_SILU", "F32", "BF16", "code", "linear", "conv3x3",
+    "bmm_nt", "conv3x3_small", "groupnorm", "layernorm", "softmax_rows", "attention",
+    "time_embedding", "gemv", "cfg_ddim_update", "post_quant", "vq_nearest", "embedding",
+    "minmax_u8", "cast",
+]
+
+_TORCH_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_WS = {}
+_WS_BYTES = 96 << 20
+
+
+def code(dtype) -> int:
+  try:
+    return _TORCH_DT[dtype]
+  except KeyError:
+    raise TypeError(f"unsupported dtype {dtype}: the HIP path stores float32 or bfloat16")
+
+
+def torch_dtype(c: int):
+  return torch.float32 if c == F32 else torch.bfloat16
+
+
+def _stream():
+  return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+  if t is None:
+    return None
+  if not t.is_cuda:
+    raise ValueError("the HIP path needs device tensors (there is no CPU fallback)")
+  return t.data_ptr()
+
+
+def _f32(t, what):
+  if t is not None and t.dtype != torch.float32:
+    raise TypeError(f"{what} must be float32")
+  return t
+
+
+def row_ld(t) -> int:
+  """Row stride (elements) of `t` seen as a 2-D [rows, cols] matrix; the leading
+  dims must collapse onto a single uniform stride (true for channel slices of
+  NHWC buffers)."""
+  if t.dim() < 2:
+    return t.shape[-1]
+  if t.shape[-1] != 1 and t.stride(-1) != 1:
+    raise ValueError("last dim must be contiguous")
+  ld = t.stride(-2)
+  for i in range(t.dim() - 2, 0, -1):
+    if t.shape[i - 1] != 1 and t.stride(i - 1) != t.stride(i) * t.shape[i]:
+      raise ValueError(f"tensor with shape {tuple(t.shape)} strides {t.stride()} has no uniform row stride")
+  return ld
+
+
+def workspace(device):
+  ws = _WS.get(device)
+  if ws is None:
+    ws = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
+    _WS[device] = ws
+  return ws
+
+
+def _gemm(p: GemmParams, device):
+  ws = workspace(device)
+  p.workspace = ws.data_ptr()
+  p.workspace_bytes = ws.numel()
+  check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
+
+
+def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_rows=0,
+           alpha=1.0, tile=0, split_k=0):
+  """out[..., n] = act(alpha * x[..., :] . wt[n, :] + bias[n] + addend[group]) + residual.
+  x [..., K]; wt [N, K] contiguous; out [..., N] (N/2 wide for GEGLU)."""
+  K = x.shape[-1]
+  N = wt.shape[0]
+  M = x.numel() // K
+  assert wt.shape[1] == K and wt.is_contiguous() and wt.dtype == x.dtype
+  p = GemmParams()
+  p.a, p.w, p.out = _ptr(x), _ptr(wt), _ptr(out)
+  p.bias = _ptr(_f32(bias, "bias"))
+  p.addend = _ptr(_f32(addend, "addend"))
+  p.residual = _ptr(residual)
+  if residual is not None:
+    assert residual.dtype == out.dtype
+    p.ldr = row_ld(residual)
+  p.lda, p.ldc_m, p.ldc_n = row_ld(x), row_ld(out), 1
+  p.M, p.N, p.K, p.batch = M, N, K, 1
+  if addend is not None:
+    p.add_rows = add_rows if add_rows > 0 else M
+    p.add_ld = addend.stride(0) if (addend.dim() == 2 and addend.shape[0] > 1) else 0
+  p.act, p.dtype, p.out_dtype, p.alpha = act, code(x.dtype), code(out.dtype), alpha
+  p.tile, p.split_k = tile, split_k
+  _gemm(p, x.device)
+  return out
+
+
+def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residual=None,
+            tile=0, split_k=0):
+  """3x3 convolution, NHWC, pad 1 (Keras SAME for stride 1; the U-Net's explicit
+  pad(1,1)+VALID for stride 2), optional fused nearest-2x upsample of the input.
+  x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout]."""
+  B, H, W, Cin = x.shape
+  Cout = wt.shape[0]
+  hs, ws_ = (2 * H, 2 * W) if upsample else (H, W)
+  OH, OW = (hs + 2 - 3) // stride + 1, (ws_ + 2 - 3) // stride + 1
+  assert wt.shape[1] == 9 * Cin and wt.is_contiguous() and wt.dtype == x.dtype
+  assert tuple(out.shape) == (B, OH, OW, Cout), (tuple(out.shape), (B, OH, OW, Cout))
+  p = GemmParams()
+  p.a, p.w, p.out = _ptr(x), _ptr(wt), _ptr(out)
+  p.bias = _ptr(_f32(bias, "bias"))
+  p.addend = _ptr(_f32(addend, "addend"))
+  p.residual = _ptr(residual)
+  if residual is not None:
+    assert residual.dtype == out.dtype
+    p.ldr = row_ld(residual)
+  p.lda, p.ldc_m, p.ldc_n = row_ld(x), row_ld(out), 1
+  p.M, p.N, p.K, p.batch = B * OH * OW, Cout, 9 * Cin, 1
+  if addend is not None:
+    p.add_rows = OH * OW
+    p.add_ld = addend.stride(0) if (addend.dim() == 2 and addend.shape[0] > 1) else 0
+  p.conv, p.B, p.H, p.W, p.Cin, p.OH, p.OW = 1, B, H, W, Cin, OH, OW
+  p.stride, p.upsample = stride, int(bool(upsample))
+  p.act, p.dtype, p.out_dtype, p.alpha = ACT_NONE, code(x.dtype), code(out.dtype), 1.0
+  p.tile, p.split_k = tile, split_k
+  _gemm(p, x.device)
+  return out
+
+
+def bmm_nt(a, w, out, alpha=1.0, bias=None, transposed_out=False, tile=0):
+  """Batched out[b] = alpha * a[b] @ w[b]^T (+bias).  a [Bt, M, K]; w [Bt, N, K] or
+  [N, K] (shared); out [Bt, M, N], or [Bt, N, ldn>=M] when transposed_out."""
+  Bt, M, K = a.shape
+  shared = w.dim() == 2
+  N = w.shape[-2]
+  assert a.stride(-1) == 1 and w.stride(-1) == 1 and out.stride(-1) == 1
+  assert w.stride(-2) == K, "weights / second operand rows must be dense"
+  p = GemmParams()
+  p.a, p.w, p.out = _ptr(a), _ptr(w), _ptr(out)
+  p.bias = _ptr(_f32(bias, "bias"))
+  p.lda = a.stride(1)
+  p.stride_a = a.stride(0)
+  p.stride_w = 0 if shared else w.stride(0)
+  p.stride_c = out.stride(0)
+  if transposed_out:
+    p.ldc_m, p.ldc_n = 1, out.stride(1)
+  else:
+    p.ldc_m, p.ldc_n = out.stride(1), 1
+  p.M, p.N, p.K, p.batch = M, N, K, Bt
+  p.act, p.dtype, p.out_dtype, p.alpha = ACT_NONE, code(a.dtype), code(out.dtype), alpha
+  p.tile = tile
+  _gemm(p, a.device)
+  return out
+
+
+def conv3x3_small(x, kernel_hwio, bias, out):
+  B, H, W, Cin = x.shape
+  Cout = kernel_hwio.shape[-1]
+  assert kernel_hwio.is_contiguous() and kernel_hwio.dtype == torch.float32
+  check(lib.ldm_conv3x3_small(_ptr(x), row_ld(x), code(x.dtype), _ptr(kernel_hwio),
+                              _ptr(_f32(bias, "bias")), _ptr(out), row_ld(out), code(out.dtype),
+                              B, H, W, Cin, Cout, _stream()), "ldm_conv3x3_small")
+  return out
+
+
+def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None):
+  """x, out [B, H, W, C] (channel slices allowed)."""
+  B, C = x.shape[0], x.shape[-1]
+  HW = x.numel() // (B * C)
+  nch = lib.ldm_groupnorm_nchunks(B, HW, C)
+  if partial is None:
+    partial = torch.empty(B * nch * groups * 2, dtype=torch.float32, device=x.device)
+  assert partial.numel() >= B * nch * groups * 2
+  dt = code(x.dtype)
+  assert out.dtype == x.dtype
+  check(lib.ldm_groupnorm_partial(_ptr(x), row_ld(x), _ptr(partial), B, HW, C, groups, nch, dt,
+                                  _stream()), "ldm_groupnorm_partial")
+  check(lib.ldm_groupnorm_apply(_ptr(x), row_ld(x), _ptr(partial), _ptr(_f32(gamma, "gamma")),
+                                _ptr(_f32(beta, "beta")), _ptr(out), row_ld(out), B, HW, C, groups,
+                                nch, float(eps), int(bool(silu)), dt, _stream()),
+        "ldm_groupnorm_apply")
+  return out
+
+
+def layernorm(x, gamma, beta, out, eps=1e-5):
+  Cc = x.shape[-1]
+  rows = x.numel() // Cc
+  assert out.dtype == x.dtype
+  check(lib.ldm_layernorm(_ptr(x), row_ld(x), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
+                          _ptr(out), row_ld(out), rows, Cc, float(eps), code(x.dtype), _stream()),
+        "ldm_layernorm")
+  return out
+
+
+def softmax_rows(x, out, scale=1.0):
+  cols = x.shape[-1]
+  rows = x.numel() // cols
+  check(lib.ldm_softmax_rows(_ptr(x), row_ld(x), code(x.dtype), _ptr(out), row_ld(out),
+                             code(out.dtype), rows, cols, float(scale), _stream()),
+        "ldm_softmax_rows")
+  return out
+
+
+def attention(q, k, vt, out, heads, sp, scale):
+  """q [R, Tq, heads*sp], k [R, Tk, heads*sp], vt [R, heads*sp, ldvt>=Tk], out like q."""
+  R, Tq = q.shape[0], q.shape[1]
+  Tk = k.shape[1]
+  assert q.dtype == k.dtype == vt.dtype == out.dtype
+  assert vt.shape[1] == heads * sp and vt.stride(2) == 1
+  check(lib.ldm_attention(_ptr(q), q.stride(1), q.stride(0), _ptr(k), k.stride(1), k.stride(0),
+                          _ptr(vt), vt.stride(1), vt.stride(0), _ptr(out), out.stride(1),
+                          out.stride(0), R, heads, Tq, Tk, sp, float(scale), code(q.dtype),
+                          _stream()), "ldm_attention")
+  return out
+
+
+def time_embedding(out, channels, t_rows=None, steps=None, index=None):
+  rows = out.shape[0]
+  check(lib.ldm_time_embedding(_ptr(t_rows), _ptr(steps), _ptr(index), _ptr(_f32(out, "out")), rows,
+                               channels, _stream()), "ldm_time_embedding")
+  return out
+
+
+def gemv(x, wt, bias, y, act_in=ACT_NONE, act_out=ACT_NONE):
+  """y[r, n] = act_out(sum_k act_in(x[r, k]) wt[n, k] + bias[n]); x, y float32."""
+  rows, K = x.shape
+  N = wt.shape[0]
+  assert wt.shape[1] == K and wt.is_contiguous()
+  check(lib.ldm_gemv(_ptr(_f32(x, "x")), x.stride(0), _ptr(wt), _ptr(_f32(bias, "bias")),
+                     _ptr(_f32(y, "y")), y.stride(0), rows, N, K, act_in, act_out, code(wt.dtype),
+                     _stream()), "ldm_gemv")
+  return y
+
+
+def cfg_ddim_update(eps_all, xt, xt_out, coef, index, guidance_scale, noise=None, x_unet_out=None,
+                    dec_index=False, clip_denoised=False):
+  B = xt.shape[0]
+  n = xt.numel() // B
+  xd = code(x_unet_out.dtype) if x_unet_out is not None else F32
+  check(lib.ldm_cfg_ddim_update(_ptr(_f32(eps_all, "eps_all")), _ptr(_f32(xt, "xt")),
+                                _ptr(_f32(noise, "noise")), _ptr(_f32(xt_out, "xt_out")),
+                                _ptr(x_unet_out), xd, _ptr(_f32(coef, "coef")), _ptr(index),
+                                int(bool(dec_index)), float(guidance_scale),
+                                int(bool(clip_denoised)), B, n, _stream()), "ldm_cfg_ddim_update")
+  return xt_out
+
+
+def post_quant(latents, scale_factor, kernel_io, bias, out):
+  Cc = latents.shape[-1]
+  check(lib.ldm_post_quant(_ptr(_f32(latents, "latents")), float(scale_factor),
+                           _ptr(_f32(kernel_io, "kernel")), _ptr(_f32(bias, "bias")), _ptr(out),
+                           code(out.dtype), latents.numel() // Cc, Cc, _stream()), "ldm_post_quant")
+  return out
+
+
+def vq_nearest(z, codebook, out, indices=None):
+  Cc = z.shape[-1]
+  check(lib.ldm_vq_nearest(_ptr(_f32(z, "z")), _ptr(_f32(codebook, "codebook")),
+                           _ptr(_f32(out, "out")), _ptr(indices), z.numel() // Cc,
+                           codebook.shape[0], Cc, _stream()), "ldm_vq_nearest")
+  return out
+
+
+def embedding(ids, tok_emb, pos_emb, out):
+  rows, T = ids.shape
+  assert ids.dtype == torch.int64 and ids.is_contiguous()
+  check(lib.ldm_embedding(_ptr(ids), _ptr(_f32(tok_emb, "tok_emb")), _ptr(_f32(pos_emb, "pos_emb")),
+                          _ptr(out), rows, T, tok_emb.shape[1], tok_emb.shape[0], code(out.dtype),
+                          _stream()), "ldm_embedding")
+  return out
+
+
+def minmax_u8(x, out, scratch=None):
+  B = x.shape[0]
+  n = x.numel() // B
+  assert x.is_contiguous() and out.dtype == torch.uint8
+  if scratch is None:
+    scratch = torch.empty(B * 128, dtype=torch.float32, device=x.device)
+  check(lib.ldm_minmax_u8(_ptr(x), code(x.dtype), _ptr(out), _ptr(scratch), B, n, _stream()),
+        "ldm_minmax_u8")
+  return out
+
+
+def cast(x, out):
+  cols = x.shape[-1]
+  rows = x.numel() // cols
+  check(lib.ldm_cast(_ptr(x), row_ld(x), code(x.dtype), _ptr(out), row_ld(out), code(out.dtype),
+                     rows, cols, _stream()), "ldm_cast")
+  return out

@@ -1,0 +1,337 @@
+"""Op-level parity of every C-ABI kernel against the CPU oracle's op restatements
+(oracle/ldm_oracle.py), through ctypes -> libldm_hip.so.  float32: tight tolerance
+(summation order differs); bfloat16: inputs are rounded to bf16 first and the
+oracle runs on the rounded values in float32, tolerance = bf16 output rounding."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ldm_oracle as O  # noqa: E402
+
+
+def ops():
+  from ldm_tf2_amd import ops as _ops
+  return _ops
+
+
+DT = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: dict(rtol=2e-4, atol=2e-4), torch.bfloat16: dict(rtol=2e-2, atol=2e-2)}
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def close(got, ref, dtype, scale=1.0):
+  got = got.detach().float().cpu()
+  ref = ref.float()
+  tol = TOL[dtype]
+  err = (got - ref).abs().max().item()
+  assert torch.allclose(got, ref, rtol=tol["rtol"], atol=tol["atol"] * scale), f"max err {err}"
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (64, 192, 1280), (1024, 64, 64)])
+def test_linear(dev, dtype, tile, M, N, K):
+  x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+  bias = rnd((N,), torch.float32, 3)
+  res = rnd((M, N), dtype, 4)
+  out = torch.empty(M, N, dtype=dtype, device=dev)
+  ops().linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), residual=res.to(dev), tile=tile)
+  ref = x.float() @ w.float().t() + bias + res.float()
+  close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("act", ["gelu", "silu", "geglu"])
+def test_linear_act_splitk(dev, dtype, act):
+  o = ops()
+  M, N, K = 96, 256, 2560
+  x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+  bias = rnd((N,), torch.float32, 3)
+  y = x.float() @ w.float().t() + bias
+  if act == "gelu":
+    ref, code, nout = O.gelu(y), o.ACT_GELU, N
+  elif act == "silu":
+    ref, code, nout = O.silu(y), o.ACT_SILU, N
+  else:
+    # device layout: blocks of 64 rows = 32 value rows then their 32 gate rows
+    yv = y.reshape(M, N // 64, 2, 32)
+    ref, code, nout = (yv[:, :, 0] * O.gelu(yv[:, :, 1])).reshape(M, N // 2), o.ACT_GEGLU, N // 2
+  for split in (1, 0, 5):
+    out = torch.zeros(M, nout, dtype=dtype, device=dev)
+    o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), act=code, split_k=split)
+    close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_linear_strided_f32out_addend(dev, dtype):
+  o = ops()
+  M, N, K = 256, 128, 192
+  buf = rnd((M, 320), dtype, 1).to(dev)
+  x = buf[:, 64:64 + K]
+  w = rnd((N, K), dtype, 2, K ** -0.5)
+  addend = rnd((4, N), torch.float32, 5)
+  outbuf = torch.zeros(M, 256, dtype=torch.float32, device=dev)
+  out = outbuf[:, 128:]
+  o.linear(x, w.to(dev), out, addend=addend.to(dev), add_rows=64, alpha=0.5)
+  ref = 0.5 * (x.float().cpu() @ w.float().t()) + addend.repeat_interleave(64, 0)
+  close(out, ref, dtype)
+  assert outbuf[:, :128].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=16, W=16, Cin=64, Cout=128, stride=1, up=False),
+    dict(B=3, H=8, W=8, Cin=128, Cout=64, stride=2, up=False),
+    dict(B=2, H=8, W=8, Cin=64, Cout=64, stride=1, up=True),
+    dict(B=1, H=4, W=4, Cin=256, Cout=320, stride=1, up=False),
+])
+def test_conv3x3(dev, dtype, cfg):
+  o = ops()
+  B, H, W, Cin, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+  x = rnd((B, H, W, Cin), dtype, 1)
+  k = rnd((3, 3, Cin, Cout), dtype, 2, (9 * Cin) ** -0.5)     # HWIO
+  bias = rnd((Cout,), torch.float32, 3)
+  addend = rnd((B, Cout), torch.float32, 4)
+  xin = O.upsample_nearest2x(x.float()) if cfg["up"] else x.float()
+  ref = O.conv2d(xin, k.float(), bias, stride=cfg["stride"]) + addend[:, None, None, :]
+  OH, OW = ref.shape[1], ref.shape[2]
+  res = rnd((B, OH, OW, Cout), dtype, 6)
+  ref = ref + res.float()
+  wt = k.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous().to(dev)
+  for tile in (0, 1, 2, 3, 4):
+    out = torch.zeros(B, OH, OW, Cout, dtype=dtype, device=dev)
+    o.conv3x3(x.to(dev), wt, out, bias=bias.to(dev), stride=cfg["stride"], upsample=cfg["up"],
+              addend=addend.to(dev), residual=res.to(dev), tile=tile)
+    close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv3x3_channel_slices(dev, dtype):
+  """input and output are channel slices of wider NHWC buffers (free skip concat)."""
+  o = ops()
+  B, H, W = 2, 8, 8
+  wide = rnd((B, H, W, 192), dtype, 1).to(dev)
+  x = wide[..., 64:192]
+  k = rnd((3, 3, 128, 64), dtype, 2, (9 * 128) ** -0.5)
+  wt = k.permute(3, 0, 1, 2).reshape(64, 9 * 128).contiguous().to(dev)
+  obuf = torch.zeros(B, H, W, 128, dtype=dtype, device=dev)
+  o.conv3x3(x, wt, obuf[..., 64:])
+  ref = O.conv2d(x.float().cpu(), k.float(), None)
+  close(obuf[..., 64:], ref, dtype)
+  assert obuf[..., :64].float().abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv3x3_small(dev, dtype):
+  o = ops()
+  x = rnd((2, 16, 16, 4), torch.float32, 1)
+  k = rnd((3, 3, 4, 64), torch.float32, 2, 0.2)
+  b = rnd((64,), torch.float32, 3)
+  out = torch.empty(2, 16, 16, 64, dtype=dtype, device=dev)
+  o.conv3x3_small(x.to(dev), k.to(dev), b.to(dev), out)
+  close(out, O.conv2d(x, k, b), dtype)
+  for cout in (3, 4):
+    x = rnd((2, 16, 16, 64), dtype, 4)
+    k = rnd((3, 3, 64, cout), torch.float32, 5, 0.05)
+    b = rnd((cout,), torch.float32, 6)
+    out = torch.empty(2, 16, 16, cout, dtype=torch.float32, device=dev)
+    o.conv3x3_small(x.to(dev), k.to(dev), b.to(dev), out)
+    close(out, O.conv2d(x.float(), k, b), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(2, 16, 16, 320), (3, 4, 4, 2560), (2, 32, 32, 64), (1, 8, 8, 960)])
+@pytest.mark.parametrize("silu", [False, True])
+def test_groupnorm(dev, dtype, shape, silu):
+  o = ops()
+  B, H, W, Cc = shape
+  x = rnd(shape, dtype, 1) * 2 + 0.5
+  gamma, beta = rnd((Cc,), torch.float32, 2) * 0.2 + 1, rnd((Cc,), torch.float32, 3) * 0.2
+  wide = torch.zeros(B, H, W, Cc + 64, dtype=dtype, device=dev)
+  xs = wide[..., 64:]
+  xs.copy_(x)
+  out = torch.empty(shape, dtype=dtype, device=dev)
+  o.groupnorm(xs, gamma.to(dev), beta.to(dev), out, eps=1e-5, silu=silu)
+  ref = O.group_norm(x.float(), gamma, beta, eps=1e-5)
+  if silu:
+    ref = O.silu(ref)
+  close(out, ref, dtype, scale=2.0)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Cc", [64, 320, 1280])
+def test_layernorm(dev, dtype, Cc):
+  o = ops()
+  x = rnd((77, Cc), dtype, 1) * 3 + 1
+  gamma, beta = rnd((Cc,), torch.float32, 2) * 0.2 + 1, rnd((Cc,), torch.float32, 3) * 0.2
+  out = torch.empty(77, Cc, dtype=dtype, device=dev)
+  o.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), out)
+  close(out, O.layer_norm(x.float(), gamma, beta), dtype, scale=2.0)
+
+
+def test_softmax_rows(dev):
+  o = ops()
+  x = rnd((50, 1000), torch.float32, 1) * 4
+  ref = torch.softmax(x * 0.3, dim=-1)
+  xd = x.to(dev)
+  outb = torch.empty(50, 1000, dtype=torch.bfloat16, device=dev)
+  o.softmax_rows(xd, outb, 0.3)
+  close(outb, ref, torch.bfloat16)
+  o.softmax_rows(xd, xd, 0.3)
+  close(xd, ref, torch.float32)
+
+
+def _attn_case(dev, dtype, R, H, S, Tq, Tk, sp):
+  o = ops()
+  q = rnd((R, Tq, H, S), dtype, 1)
+  k = rnd((R, Tk, H, S), dtype, 2)
+  v = rnd((R, Tk, H, S), dtype, 3)
+  scale = S ** -0.5
+  logits = torch.einsum("nqhs,nchs->nhqc", q.float(), k.float()) * scale
+  ref = torch.einsum("nhqc,nchs->nqhs", torch.softmax(logits, dim=3), v.float())
+  pad = lambda t: torch.nn.functional.pad(t, (0, sp - S))
+  qd = pad(q).reshape(R, Tq, H * sp).to(dev)
+  kd = pad(k).reshape(R, Tk, H * sp).to(dev)
+  tkp = (Tk + 7) // 8 * 8
+  vt = torch.zeros(R, H * sp, tkp, dtype=dtype)
+  vt[:, :, :Tk] = pad(v).reshape(R, Tk, H * sp).permute(0, 2, 1)
+  out = torch.full((R, Tq, H * sp), float("nan"), dtype=dtype, device=dev)
+  o.attention(qd, kd, vt.to(dev), out, H, sp, scale)
+  got = out.reshape(R, Tq, H, sp)
+  close(got[..., :S], ref, dtype)
+  assert got[..., S:].float().abs().max().item() == 0 if sp > S else True
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [
+    dict(R=2, H=8, S=40, Tq=256, Tk=256, sp=64),
+    dict(R=2, H=8, S=40, Tq=256, Tk=77, sp=64),
+    dict(R=1, H=4, S=80, Tq=64, Tk=64, sp=96),
+    dict(R=2, H=2, S=160, Tq=16, Tk=16, sp=160),
+    dict(R=1, H=2, S=160, Tq=64, Tk=77, sp=160),
+    dict(R=2, H=8, S=64, Tq=77, Tk=77, sp=64),
+    dict(R=1, H=8, S=8, Tq=200, Tk=130, sp=32),
+])
+def test_attention(dev, dtype, case):
+  _attn_case(dev, dtype, **case)
+
+
+def test_attention_spike(dev):
+  """forces the online-softmax rescale: one key dominates late in the sequence."""
+  o = ops()
+  R, H, S, T, sp = 1, 1, 64, 256, 64
+  q = rnd((R, T, H, S), torch.float32, 1)
+  k = rnd((R, T, H, S), torch.float32, 2)
+  v = rnd((R, T, H, S), torch.float32, 3)
+  k[0, 200, 0] = q[0, 5, 0] * 4
+  scale = S ** -0.5
+  logits = torch.einsum("nqhs,nchs->nhqc", q, k) * scale
+  ref = torch.einsum("nhqc,nchs->nqhs", torch.softmax(logits, dim=3), v)
+  out = torch.empty(R, T, H * sp, device=dev)
+  o.attention(q.reshape(R, T, S).to(dev), k.reshape(R, T, S).to(dev),
+              v.reshape(R, T, S).permute(0, 2, 1).contiguous().to(dev), out, H, sp, scale)
+  close(out.reshape(R, T, H, sp), ref, torch.float32)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bmm_nt_and_transposed(dev, dtype):
+  o = ops()
+  a, w = rnd((3, 100, 128), dtype, 1), rnd((3, 80, 128), dtype, 2, 0.1)
+  out = torch.empty(3, 100, 80, dtype=torch.float32, device=dev)
+  o.bmm_nt(a.to(dev), w.to(dev), out, alpha=0.25)
+  close(out, 0.25 * torch.einsum("bmk,bnk->bmn", a.float(), w.float()), dtype)
+  ws = rnd((96, 128), dtype, 3, 0.1)
+  outT = torch.zeros(3, 96, 104, dtype=dtype, device=dev)
+  o.bmm_nt(a.to(dev), ws.to(dev), outT, transposed_out=True)
+  ref = torch.einsum("bmk,nk->bnm", a.float(), ws.float())
+  close(outT[:, :, :100], ref, dtype)
+  assert outT[:, :, 100:].float().abs().max().item() == 0
+
+
+def test_time_embedding_gemv(dev):
+  o = ops()
+  t = torch.tensor([981, 1, 500], dtype=torch.int32)
+  out = torch.empty(3, 320, device=dev)
+  o.time_embedding(out, 320, t_rows=t.to(dev))
+  ref = O.get_time_embedding(t.numpy(), 320)
+  assert torch.allclose(out.cpu(), ref, atol=2e-4, rtol=0)
+  steps = torch.arange(1, 1000, 20, dtype=torch.int32, device=dev)
+  idx = torch.tensor([49], dtype=torch.int32, device=dev)
+  o.time_embedding(out, 320, steps=steps, index=idx)
+  assert torch.allclose(out.cpu(), ref[0:1].expand(3, -1), atol=2e-4, rtol=0)
+  for dtype in DT:
+    x = rnd((3, 320), torch.float32, 1)
+    w = rnd((1280, 320), dtype, 2, 0.05)
+    b = rnd((1280,), torch.float32, 3)
+    y = torch.empty(3, 1280, device=dev)
+    o.gemv(x.to(dev), w.to(dev), b.to(dev), y, act_in=o.ACT_SILU, act_out=o.ACT_SILU)
+    close(y, O.silu(O.silu(x) @ w.float().t() + b), torch.float32)
+
+
+def test_cfg_ddim_update(dev):
+  o = ops()
+  sched = O.make_schedule(1000, 0.00085, 0.012, 0.7, 50)
+  coef = np.stack([sched["ddim_sqrt_recip_alphas_cumprod"], sched["ddim_sqrt_recipm1_alphas_cumprod"],
+                   sched["ddim_alphas_cumprod_prev"], sched["ddim_sigmas"]], 1).astype(np.float32)
+  B = 3
+  eps = rnd((2 * B, 8, 8, 4), torch.float32, 1)
+  xt = rnd((B, 8, 8, 4), torch.float32, 2)
+  noise = rnd((B, 8, 8, 4), torch.float32, 3)
+  idx = torch.tensor([17], dtype=torch.int32, device=dev)
+  xo = torch.empty(B, 8, 8, 4, device=dev)
+  xu = torch.empty(2 * B, 8, 8, 4, dtype=torch.bfloat16, device=dev)
+  o.cfg_ddim_update(eps.to(dev), xt.to(dev), xo, torch.from_numpy(coef).to(dev), idx, 5.0,
+                    noise=noise.to(dev), x_unet_out=xu, dec_index=True)
+  ref, _ = O.ddim_update(xt, eps[:B], eps[B:], sched, 17, 5.0, noise)
+  assert torch.allclose(xo.cpu(), ref, rtol=1e-5, atol=1e-5)
+  assert idx.item() == 16
+  assert torch.equal(xu[:B].cpu(), ref.to(torch.bfloat16)) or torch.allclose(
+      xu[:B].float().cpu(), ref, rtol=1e-2, atol=1e-2)
+  assert torch.equal(xu[:B], xu[B:])
+
+
+def test_post_quant_vq_embedding_minmax_cast(dev):
+  o = ops()
+  z = rnd((2, 8, 8, 4), torch.float32, 1)
+  k, b = rnd((4, 4), torch.float32, 2), rnd((4,), torch.float32, 3)
+  out = torch.empty(2, 8, 8, 4, device=dev)
+  o.post_quant(z.to(dev), 0.18215, k.to(dev), b.to(dev), out)
+  assert torch.allclose(out.cpu(), O.dense(z / 0.18215, k, b), rtol=1e-5, atol=1e-5)
+  cb = rnd((1000, 4), torch.float32, 4)
+  q = torch.empty(2, 8, 8, 4, device=dev)
+  ind = torch.empty(128, dtype=torch.int64, device=dev)
+  o.vq_nearest(z.to(dev), cb.to(dev), q, ind)
+  qr, ir = O.vq_nearest(z, cb)
+  assert torch.equal(ind.cpu(), ir)
+  assert torch.allclose(q.cpu(), qr, rtol=1e-6, atol=1e-6)
+  ids = torch.randint(0, 500, (3, 77), generator=torch.Generator().manual_seed(0))
+  tok, pos = rnd((500, 64), torch.float32, 5), rnd((77, 64), torch.float32, 6)
+  e = torch.empty(3, 77, 64, device=dev)
+  o.embedding(ids.to(dev), tok.to(dev), pos.to(dev), e)
+  assert torch.equal(e.cpu(), tok[ids] + pos[None])
+  img = rnd((3, 32, 32, 3), torch.float32, 7)
+  u8 = torch.empty(3, 32, 32, 3, dtype=torch.uint8, device=dev)
+  o.minmax_u8(img.to(dev), u8)
+  ref = O.tensor_to_image(img.numpy())
+  diff = np.abs(u8.cpu().numpy().astype(int) - ref.astype(int))
+  assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+  c = torch.empty(3, 32, 32, 3, dtype=torch.bfloat16, device=dev)
+  o.cast(img.to(dev), c)
+  assert torch.equal(c.cpu(), img.to(torch.bfloat16))
+
+
+def test_error_reporting(dev):
+  from ldm_tf2_amd._lib import LdmHipError
+  o = ops()
+  x = torch.zeros(8, 100, device=dev)          # K=100 ok for f32, Cin check fails for conv
+  with pytest.raises(LdmHipError):
+    o.conv3x3(torch.zeros(1, 4, 4, 20, device=dev), torch.zeros(8, 180, device=dev),
+              torch.zeros(1, 4, 4, 8, device=dev))
