@@ -169,14 +169,18 @@ int ldm_gemv(const float* x, int64_t ldx, const void* wt, const float* bias, flo
  * Classifier-free guidance + DDIM update, float32 (model_runners.py:451-468):
  *   eps = eps_u + s*(eps_c - eps_u); x0 = c1*xt - c2*eps; mean = sqrt(a_prev)*x0
  *   + sqrt(1 - a_prev - sigma^2)*eps; xt' = mean + noise*sigma.
- * eps_all [2B][n] (uncond rows first), xt/xt_out/noise [B][n] (noise may be NULL when
- * sigma = 0).  coef = device table [N_steps][4] of float32 (c1, c2, a_prev, sigma)
- * gathered at *index (the `_extract` cast-then-gather, :41-44).  If `dec_index` != 0
- * the kernel decrements *index afterwards (device-side loop counter for graph replay).
+ * eps_all [2B][n] (uncond rows first), xt/xt_out [B][n]; noise (may be NULL when
+ * sigma = 0) is read at noise + (*index) * noise_index_stride, i.e. a [N_steps][B][n]
+ * table indexed by the DDIM index (stride 0 = one [B][n] buffer).
+ * coef = device table [N_steps][4] of float32 (c1, c2, a_prev, sigma) gathered at
+ * *index (the `_extract` cast-then-gather, :41-44).  If `dec_index` != 0 *index is
+ * decremented afterwards (device-side loop counter for graph replay).
+ * pred_x0_out (optional) receives x0 (:455-460, `return_pred_x0`).
  * x_unet_out (optional, dtype x_dtype) receives concat([xt', xt']) for the next step
  * (:452) so the next U-Net call reads it directly.
  */
-int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const float* noise, float* xt_out,
+int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const float* noise,
+                        int64_t noise_index_stride, float* xt_out, float* pred_x0_out,
                         void* x_unet_out, int x_dtype, const float* coef, int32_t* index,
                         int dec_index, float guidance_scale, int clip_denoised, int B,
                         int64_t n_per_sample, void* stream);

@@ -57,7 +57,7 @@ SIGNATURES = {
     "ldm_time_embedding": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "ldm_gemv": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32,
                          c_i32, c_i32, c_vp]),
-    "ldm_cfg_ddim_update": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32,
+    "ldm_cfg_ddim_update": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32,
                                     c_f32, c_i32, c_i32, c_i64, c_vp]),
     "ldm_post_quant": (c_i32, [c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "ldm_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),

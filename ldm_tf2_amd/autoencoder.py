@@ -1,0 +1,228 @@
+"""First-stage decoders on the HIP path -- host side (decode only).
+
+Mirrors `AutoencoderKL.decode` (autoencoder.py:361-364) and `AutoencoderVQ.decode`
+(:430-436) with the reference constructors' kwargs (= YAML `autoencoder_kl` /
+`autoencoder_vq`).  `decode(latents f32 [B,h,w,4]) -> f32 [B,8h,8w,3]`, NHWC.
+Encoders are out of scope (training / img2latent only).
+
+VQ: the reference binds the quantizer's 3-tuple to `latents` (:432), which cannot
+run; the intended element 0 (the quantised latents) is used.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import layout as L
+from . import ops
+from .weights import decoder_manifest, init_weights
+
+GROUP_NORM_EPS = 1e-6   # autoencoder.py:11
+
+
+class _Res:
+  def __init__(self, w, p, dtype, dev):
+    g = lambda n: w[p + "/" + n]
+    self.cin, self.cout = g("conv1/kernel").shape[2], g("conv1/kernel").shape[3]
+    self.gn1 = (L.vec(g("group_norm1/gamma"), dev), L.vec(g("group_norm1/beta"), dev))
+    self.conv1 = (L.conv_kernel(g("conv1/kernel"), dtype, dev), L.vec(g("conv1/bias"), dev))
+    self.gn2 = (L.vec(g("group_norm2/gamma"), dev), L.vec(g("group_norm2/beta"), dev))
+    self.conv2 = (L.conv_kernel(g("conv2/kernel"), dtype, dev), L.vec(g("conv2/bias"), dev))
+    self.shortcut = None
+    if (p + "/shortcut/kernel") in w:
+      self.shortcut = (L.dense_kernel(g("shortcut/kernel"), dtype, dev), L.vec(g("shortcut/bias"), dev))
+
+
+class _Attn:
+  def __init__(self, w, p, dtype, dev):
+    g = lambda n: w[p + "/" + n]
+    self.gn = (L.vec(g("group_norm/gamma"), dev), L.vec(g("group_norm/beta"), dev))
+    d = lambda n: (L.dense_kernel(g(n + "/kernel"), dtype, dev), L.vec(g(n + "/bias"), dev))
+    self.q, self.k, self.v, self.o = d("dense_query"), d("dense_key"), d("dense_value"), d("dense_output")
+    self.c = g("dense_query/kernel").shape[0]
+
+
+class _Decoder:
+  """Decoder (autoencoder.py:252-298) + post_quant_conv (+ VQ codebook)."""
+
+  def __init__(self, weights, dtype, device, attention_resolutions):
+    w, dev = weights, device
+    self.dtype, self.device = dtype, dev
+    self.attention_resolutions = tuple(attention_resolutions)
+    self.codebook = L.vec(w["quantize/kernel"], dev) if "quantize/kernel" in w else None
+    self.post_quant = (L.vec(w["post_quant_conv/kernel"], dev), L.vec(w["post_quant_conv/bias"], dev))
+    self.conv_in = (L.vec(w["decoder/conv_in/kernel"], dev), L.vec(w["decoder/conv_in/bias"], dev))
+    self.mid = (_Res(w, "decoder/middle/residual1", dtype, dev),
+                _Attn(w, "decoder/middle/attention", dtype, dev),
+                _Res(w, "decoder/middle/residual2", dtype, dev))
+    self.up = []
+    i = 0
+    while any(k.startswith(f"decoder/up/{i}/") for k in w):
+      p = f"decoder/up/{i}"
+      if (p + "/conv/kernel") in w:
+        self.up.append(("up", L.conv_kernel(w[p + "/conv/kernel"], dtype, dev), L.vec(w[p + "/conv/bias"], dev)))
+      else:
+        a = _Attn(w, p + "/attention", dtype, dev) if (p + "/attention/group_norm/gamma") in w else None
+        self.up.append(("res", _Res(w, p + "/residual", dtype, dev), a))
+      i += 1
+    self.gn_out = (L.vec(w["decoder/group_norm/gamma"], dev), L.vec(w["decoder/group_norm/beta"], dev))
+    self.conv_out = (L.vec(w["decoder/conv_out/kernel"], dev), L.vec(w["decoder/conv_out/bias"], dev))
+    self.buf = L.Buffers(dev)
+
+  def _res(self, r, x, out):
+    """autoencoder.py:42-58 with time=None."""
+    B_, dt = self.buf, self.dtype
+    B, h, w, _ = x.shape
+    t0 = B_.get("gn", (B, h, w, r.cin), dt)
+    ops.groupnorm(x, r.gn1[0], r.gn1[1], t0, GROUP_NORM_EPS, silu=True, partial=self._gnp)
+    h1 = B_.get("h1", (B, h, w, r.cout), dt)
+    ops.conv3x3(t0, r.conv1[0], h1, bias=r.conv1[1])
+    t1 = B_.get("gn", (B, h, w, r.cout), dt)
+    ops.groupnorm(h1, r.gn2[0], r.gn2[1], t1, GROUP_NORM_EPS, silu=True, partial=self._gnp)
+    res = x
+    if r.shortcut is not None:
+      res = B_.get("sc", (B, h, w, r.cout), dt)
+      ops.linear(x, r.shortcut[0], res, bias=r.shortcut[1])
+    ops.conv3x3(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
+    return out
+
+  def _attn(self, a, x, out):
+    """autoencoder.py:74-97: single head over all H*W positions, head dim = C.
+    C = 512 is beyond the fused kernel's head sizes, and this block runs once per
+    image, so logits are materialised: q.k^T (batched MFMA GEMM, f32 out) ->
+    row softmax with the C**-0.5 scale -> P.V (batched GEMM against V^T)."""
+    B_, dt = self.buf, self.dtype
+    B, h, w, c = x.shape
+    T = h * w
+    t0 = B_.get("gn", (B, h, w, c), dt)
+    ops.groupnorm(x, a.gn[0], a.gn[1], t0, GROUP_NORM_EPS, silu=False, partial=self._gnp)
+    q = B_.get("at_q", (B, T, c), dt)
+    k = B_.get("at_k", (B, T, c), dt)
+    vt = B_.get("at_vt", (B, c, T), dt)
+    ops.linear(t0, a.q[0], q, bias=a.q[1])
+    ops.linear(t0, a.k[0], k, bias=a.k[1])
+    ops.bmm_nt(t0.reshape(B, T, c), a.v[0], vt, bias=a.v[1], transposed_out=True)
+    logits = B_.get("at_logits", (B, T, T), torch.float32)
+    ops.bmm_nt(q, k, logits)
+    p = B_.get("at_p", (B, T, T), dt)
+    ops.softmax_rows(logits, p, scale=c ** -0.5)
+    o = B_.get("at_o", (B, T, c), dt)
+    ops.bmm_nt(p, vt, o)
+    ops.linear(o, a.o[0], out, bias=a.o[1], residual=x)
+    return out
+
+  def _dst(self, cur, shape):
+    """Ping-pong activation buffer of `shape` that is not `cur`."""
+    t = self.buf.get("act_a", shape, self.dtype)
+    if cur is not None and t.data_ptr() == cur.data_ptr():
+      t = self.buf.get("act_b", shape, self.dtype)
+    return t
+
+  def decode(self, latents, scale_factor=1.0, force_quantize=False):
+    """latents f32 [B,h,w,C]; computes Decoder(post_quant(quantize?(latents / scale_factor)))."""
+    assert latents.dtype == torch.float32 and latents.is_contiguous()
+    B_, dt = self.buf, self.dtype
+    B, h, w, c = latents.shape
+    self._gnp = B_.get("gn_partial", (B * 128 * 32 * 2,), torch.float32)
+    z = latents
+    sf = scale_factor
+    if force_quantize:
+      if self.codebook is None:
+        raise ValueError("force_quantize needs a VQ codebook")
+      zs = B_.get("zs", (B, h, w, c), torch.float32)
+      # quantise latents/scale_factor: scale with an identity post_quant, then look up
+      eye = B_.get("eye", (c, c), torch.float32, zero=True)
+      if not getattr(self, "_eye_ok", False):
+        eye.copy_(torch.eye(c))
+        self._eye_ok = True
+      ops.post_quant(z, sf, eye, None, zs)
+      zq = B_.get("zq", (B, h, w, c), torch.float32)
+      ops.vq_nearest(zs, self.codebook, zq)
+      z, sf = zq, 1.0
+    x0 = B_.get("pq", (B, h, w, c), torch.float32)
+    ops.post_quant(z, sf, self.post_quant[0], self.post_quant[1], x0)
+    ch = self.mid[0].cin
+    cur = self._dst(None, (B, h, w, ch))
+    ops.conv3x3_small(x0, self.conv_in[0], self.conv_in[1], cur)
+    cur = self._res(self.mid[0], cur, self._dst(cur, (B, h, w, ch)))
+    cur = self._attn(self.mid[1], cur, self._dst(cur, (B, h, w, ch)))   # always (autoencoder.py:193)
+    cur = self._res(self.mid[2], cur, self._dst(cur, (B, h, w, ch)))
+    for blk in self.up:
+      hh, ww = cur.shape[1], cur.shape[2]
+      if blk[0] == "up":
+        dst = self._dst(cur, (B, 2 * hh, 2 * ww, blk[1].shape[0]))
+        cur = ops.conv3x3(cur, blk[1], dst, bias=blk[2], upsample=True)   # autoencoder.py:152-155
+      else:
+        _, r, a = blk
+        cur = self._res(r, cur, self._dst(cur, (B, hh, ww, r.cout)))
+        if a is not None and hh in self.attention_resolutions:            # autoencoder.py:176
+          cur = self._attn(a, cur, self._dst(cur, (B, hh, ww, r.cout)))
+    t0 = B_.get("gn", tuple(cur.shape), dt)
+    ops.groupnorm(cur, self.gn_out[0], self.gn_out[1], t0, GROUP_NORM_EPS, silu=True, partial=self._gnp)
+    out = torch.empty(B, cur.shape[1], cur.shape[2], self.conv_out[0].shape[-1], dtype=torch.float32,
+                      device=self.device)
+    ops.conv3x3_small(t0, self.conv_out[0], self.conv_out[1], out)
+    return out
+
+
+class _AutoencoderBase:
+  _is_vq = False
+
+  def _build(self, man_kwargs, weights, dtype, device, init, seed, attention_resolutions):
+    self.dtype, self.device = dtype, torch.device(device)
+    self.manifest = decoder_manifest(**man_kwargs)
+    if weights is None:
+      weights = init_weights(self.manifest, seed=seed, mode=init, scope="autoencoder")
+    missing = [k for k in self.manifest if k not in weights]
+    if missing:
+      raise KeyError(f"autoencoder weights missing {len(missing)} tensors, e.g. {missing[:3]}")
+    self._decoder = _Decoder(weights, dtype, self.device, attention_resolutions)
+
+  def encode(self, *a, **k):
+    raise NotImplementedError("encode is outside the sampling path (SURVEY.md section 8f, N4)")
+
+
+class AutoencoderKL(_AutoencoderBase):
+  """kwargs of autoencoder.py:302-311.  `attention_resolutions` is accepted and
+  ignored exactly as the reference does (it passes `()` to its Decoder, :339)."""
+
+  def __init__(self, latent_channels=4, channels=128, num_blocks=2, attention_resolutions=(),
+               dropout_rate=0., multipliers=(1, 2, 4, 4), resample_with_conv=True, *,
+               weights=None, dtype=torch.float32, device="cuda:0", init="keras", seed=2):
+    if not resample_with_conv:
+      raise NotImplementedError("resample_with_conv=False is not on the sampling path")
+    self._latent_channels, self._channels, self._num_blocks = latent_channels, channels, num_blocks
+    self._multipliers = tuple(multipliers)
+    self._build(dict(latent_channels=latent_channels, channels=channels, num_blocks=num_blocks,
+                     multipliers=self._multipliers, attention_resolutions=()),
+                weights, dtype, device, init, seed, ())
+
+  def decode(self, inputs, training=False, scale_factor=1.0):
+    """autoencoder.py:361-364."""
+    x = torch.as_tensor(inputs, dtype=torch.float32).to(self.device).contiguous()
+    return self._decoder.decode(x, scale_factor=scale_factor)
+
+
+class AutoencoderVQ(_AutoencoderBase):
+  """kwargs of autoencoder.py:371-383.  `latent_size` (build-only) is the spatial
+  size at which the decoder will run: it decides which UpBlocks own attention
+  weights (autoencoder.py:176 tests the run-time size)."""
+  _is_vq = True
+
+  def __init__(self, latent_channels=4, channels=128, num_blocks=2, dropout_rate=0,
+               multipliers=(1, 2, 2, 4), resample_with_conv=True, attention_resolutions=(32,),
+               vocab_size=16384, beta=0.25, *, latent_size=32, weights=None,
+               dtype=torch.float32, device="cuda:0", init="keras", seed=2):
+    if not resample_with_conv:
+      raise NotImplementedError("resample_with_conv=False is not on the sampling path")
+    self._latent_channels, self._channels, self._num_blocks = latent_channels, channels, num_blocks
+    self._multipliers, self._vocab_size, self._beta = tuple(multipliers), vocab_size, beta
+    self._attention_resolutions = tuple(attention_resolutions)
+    self._build(dict(latent_channels=latent_channels, channels=channels, num_blocks=num_blocks,
+                     multipliers=self._multipliers, attention_resolutions=self._attention_resolutions,
+                     latent_size=latent_size, vocab_size=vocab_size),
+                weights, dtype, device, init, seed, self._attention_resolutions)
+
+  def decode(self, latents, force_quantize=False, training=False, scale_factor=1.0):
+    """autoencoder.py:430-436."""
+    x = torch.as_tensor(latents, dtype=torch.float32).to(self.device).contiguous()
+    return self._decoder.decode(x, scale_factor=scale_factor, force_quantize=force_quantize)

@@ -176,11 +176,14 @@ template <typename TX>
 __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__ eps_all,
                                                        const float* __restrict__ xt,
                                                        const float* __restrict__ noise,
+                                                       int64_t noise_stride,
                                                        float* __restrict__ xt_out,
+                                                       float* __restrict__ pred_x0_out,
                                                        TX* __restrict__ x_unet, const float* coef,
                                                        int32_t* index, int dec_index, float gs,
                                                        int clip, int B, int64_t n) {
   const int idx = *index;
+  if (noise) noise += (int64_t)idx * noise_stride;
   const float c1 = coef[idx * 4 + 0], c2 = coef[idx * 4 + 1];
   const float a_prev = coef[idx * 4 + 2], sigma = coef[idx * 4 + 3];
   const float sa = sqrtf(a_prev);
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__
     const float mean = sa * x0 + sb * eps;
     const float o = mean + (noise ? noise[i] : 0.f) * sigma;
     xt_out[i] = o;
+    if (pred_x0_out) pred_x0_out[i] = x0;
     if (x_unet) { stf<TX>(x_unet + i, o); stf<TX>(x_unet + total + i, o); }
   }
 }
@@ -414,7 +418,8 @@ extern "C" int ldm_gemv(const float* x, int64_t ldx, const void* wt, const float
 }
 
 extern "C" int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const float* noise,
-                                   float* xt_out, void* x_unet_out, int x_dtype, const float* coef,
+                                   int64_t noise_index_stride, float* xt_out, float* pred_x0_out,
+                                   void* x_unet_out, int x_dtype, const float* coef,
                                    int32_t* index, int dec_index, float guidance_scale,
                                    int clip_denoised, int B, int64_t n_per_sample, void* stream) {
   LDM_CHECK_ARG(eps_all && xt && xt_out && coef && index, "ldm_cfg_ddim_update: null pointer");
@@ -422,11 +427,11 @@ extern "C" int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const 
   hipStream_t s = (hipStream_t)stream;
   dim3 g(grid_for((int64_t)B * n_per_sample, 256, 1024));
   if (x_dtype == LDM_BF16)
-    hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, g, dim3(256), 0, s, eps_all, xt, noise, xt_out,
+    hipLaunchKernelGGL(cfg_ddim_kernel<bf16_t>, g, dim3(256), 0, s, eps_all, xt, noise, noise_index_stride, xt_out, pred_x0_out,
                        (bf16_t*)x_unet_out, coef, index, dec_index, guidance_scale, clip_denoised, B,
                        n_per_sample);
   else
-    hipLaunchKernelGGL(cfg_ddim_kernel<float>, g, dim3(256), 0, s, eps_all, xt, noise, xt_out,
+    hipLaunchKernelGGL(cfg_ddim_kernel<float>, g, dim3(256), 0, s, eps_all, xt, noise, noise_index_stride, xt_out, pred_x0_out,
                        (float*)x_unet_out, coef, index, dec_index, guidance_scale, clip_denoised, B,
                        n_per_sample);
   int st = ldm_launch_status("ldm_cfg_ddim_update");

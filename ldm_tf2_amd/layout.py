@@ -1,0 +1,98 @@
+"""Re-layout ("compile") of reference-layout master weights into the device
+layouts the HIP kernels consume, plus the scratch-buffer cache the host models use.
+
+Reference layouts (weights.py)          -> device layouts (include/ldm_hip.h)
+  conv kernel HWIO [3,3,Cin,Cout]       -> OHWI matrix [Cout, 9*Cin]   (K contiguous)
+  Dense kernel [in, out]                -> [out, in]
+  Projection split kernel [D, H, S]     -> [H*Sp, D], rows s >= S of each head zero
+  Projection merge kernel [H, S, D]     -> [D, H*Sp], columns s >= S zero
+  GEGLU Dense [C, 8C] (value | gate)    -> [8C, C] rows in blocks of 64:
+                                           32 value rows then their 32 gate rows
+Sp = head size padded up to the next size the attention kernel is built for
+(zero padding contributes nothing to q.k^T and yields zero output columns).
+This is plumbing done once at model-build time with torch tensor ops on the host;
+no sampling-path arithmetic happens here.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+ATTN_SP = (32, 64, 96, 160)   # padded head sizes instantiated in attention.hip
+
+
+def padded_head(s: int) -> int:
+  for sp in ATTN_SP:
+    if s <= sp:
+      return sp
+  raise ValueError(f"head size {s} > {ATTN_SP[-1]} is not supported by the fused attention kernel")
+
+
+def _dev(a, dtype, device):
+  t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+  return t.to(dtype).contiguous().to(device)
+
+
+def conv_kernel(k_hwio, dtype, device):
+  k = torch.from_numpy(np.ascontiguousarray(k_hwio))
+  cout = k.shape[3]
+  return _dev(k.permute(3, 0, 1, 2).reshape(cout, -1), dtype, device)
+
+
+def dense_kernel(k_io, dtype, device):
+  return _dev(torch.from_numpy(np.ascontiguousarray(k_io)).t(), dtype, device)
+
+
+def split_kernel(k_dhs, sp, dtype, device):
+  k = torch.from_numpy(np.ascontiguousarray(k_dhs))          # [D, H, S]
+  d, h, s = k.shape
+  out = torch.zeros(h, sp, d, dtype=k.dtype)
+  out[:, :s, :] = k.permute(1, 2, 0)
+  return _dev(out.reshape(h * sp, d), dtype, device)
+
+
+def merge_kernel(k_hsd, sp, dtype, device):
+  k = torch.from_numpy(np.ascontiguousarray(k_hsd))          # [H, S, D]
+  h, s, d = k.shape
+  out = torch.zeros(d, h, sp, dtype=k.dtype)
+  out[:, :, :s] = k.permute(2, 0, 1)
+  return _dev(out.reshape(d, h * sp), dtype, device)
+
+
+def geglu_kernel(k_io, bias, dtype, device):
+  k = torch.from_numpy(np.ascontiguousarray(k_io))           # [C, 8C]
+  c, n = k.shape
+  half = n // 2
+  assert half % 32 == 0, "GEGLU width must be a multiple of 32"
+  wt = k.t()                                                  # [8C, C]; rows: value | gate
+  val, gate = wt[:half].reshape(half // 32, 32, c), wt[half:].reshape(half // 32, 32, c)
+  inter = torch.stack([val, gate], dim=1).reshape(n, c)
+  b = torch.from_numpy(np.ascontiguousarray(bias))
+  bi = torch.stack([b[:half].reshape(-1, 32), b[half:].reshape(-1, 32)], dim=1).reshape(n)
+  return _dev(inter, dtype, device), _dev(bi, torch.float32, device)
+
+
+def vec(a, device):
+  return _dev(a, torch.float32, device)
+
+
+class Buffers:
+  """Scratch tensors keyed by (tag, shape, dtype); allocated once, reused by every
+  later call with the same key.  All kernels of one model run on one stream in
+  program order, so a tag only needs to be unique among tensors that are live at
+  the same time."""
+
+  def __init__(self, device):
+    self.device = device
+    self._b = {}
+
+  def get(self, tag, shape, dtype, zero=False):
+    key = (tag, tuple(int(s) for s in shape), dtype)
+    t = self._b.get(key)
+    if t is None:
+      t = (torch.zeros if zero else torch.empty)(key[1], dtype=dtype, device=self.device)
+      self._b[key] = t
+    return t
+
+  def nbytes(self):
+    return sum(t.numel() * t.element_size() for t in self._b.values())

@@ -250,12 +250,13 @@ def gemv(x, wt, bias, y, act_in=ACT_NONE, act_out=ACT_NONE):
 
 
 def cfg_ddim_update(eps_all, xt, xt_out, coef, index, guidance_scale, noise=None, x_unet_out=None,
-                    dec_index=False, clip_denoised=False):
+                    dec_index=False, clip_denoised=False, noise_index_stride=0, pred_x0_out=None):
   B = xt.shape[0]
   n = xt.numel() // B
   xd = code(x_unet_out.dtype) if x_unet_out is not None else F32
   check(lib.ldm_cfg_ddim_update(_ptr(_f32(eps_all, "eps_all")), _ptr(_f32(xt, "xt")),
-                                _ptr(_f32(noise, "noise")), _ptr(_f32(xt_out, "xt_out")),
+                                _ptr(_f32(noise, "noise")), int(noise_index_stride),
+                                _ptr(_f32(xt_out, "xt_out")), _ptr(_f32(pred_x0_out, "pred_x0_out")),
                                 _ptr(x_unet_out), xd, _ptr(_f32(coef, "coef")), _ptr(index),
                                 int(bool(dec_index)), float(guidance_scale),
                                 int(bool(clip_denoised)), B, n, _stream()), "ldm_cfg_ddim_update")

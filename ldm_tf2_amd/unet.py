@@ -1,0 +1,333 @@
+"""Conditioning U-Net on the HIP path -- host side.
+
+Mirrors the reference's `UNet` operator (unet.py:51-138): same constructor
+kwargs (= the YAML `unet` section), same call contract
+`unet(x f32[R,h,w,4], t int32[R], context [R,77,D]) -> f32[R,h,w,4]`, NHWC.
+The arithmetic runs in hand-written HIP kernels through the C ABI
+(include/ldm_hip.h); this file only walks the block structure and hands out
+buffers.  There is no CPU path.
+
+What the host does differently from a line-by-line transcription (none of it
+changes results beyond float rounding order):
+  * the skip concatenation (unet.py:135) is free: every skip tensor and every
+    block output is written straight into its channel slice of the buffer the
+    consuming output block reads;
+  * the timestep MLP (unet.py:126-127) and the 22 ResBlock temb projections
+    (unet.py:386) depend only on t: they run once per call as four skinny-Dense
+    launches; when all rows share one t (the DDIM loop, model_runners.py:449)
+    they run for a single row;
+  * cross-attention K and V of the text context (unet.py:274-275 with
+    context != None) are step-invariant: `set_context` computes them once;
+  * nearest-2x upsample (unet.py:44) is fused into the following conv's gather.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import layout as L
+from . import ops
+from .weights import init_weights, unet_manifest
+
+GN_EPS_RES = 1e-5   # unet.py:374,377,115
+GN_EPS_ST = 1e-6    # unet.py:354
+LN_EPS = 1e-5       # unet.py:304-306
+
+
+class _Res:
+  """ResidualBlock weights (unet.py:368-380)."""
+
+  def __init__(self, w, p, dtype, dev):
+    g = lambda n: w[p + "/" + n]
+    self.cin, self.cout = g("conv2d_1/kernel").shape[2], g("conv2d_1/kernel").shape[3]
+    self.gn1 = (L.vec(g("group_norm_1/gamma"), dev), L.vec(g("group_norm_1/beta"), dev))
+    self.conv1 = (L.conv_kernel(g("conv2d_1/kernel"), dtype, dev), L.vec(g("conv2d_1/bias"), dev))
+    self.temb_k, self.temb_b = g("dense/kernel"), g("dense/bias")   # gathered by the U-Net
+    self.gn2 = (L.vec(g("group_norm_2/gamma"), dev), L.vec(g("group_norm_2/beta"), dev))
+    self.conv2 = (L.conv_kernel(g("conv2d_2/kernel"), dtype, dev), L.vec(g("conv2d_2/bias"), dev))
+    self.shortcut = None
+    if (p + "/shortcut/kernel") in w:
+      self.shortcut = (L.dense_kernel(g("shortcut/kernel"), dtype, dev), L.vec(g("shortcut/bias"), dev))
+    self.temb_off = 0
+
+
+class _ST:
+  """SpatialTransformer weights (unet.py:341-354, :295-306, :248-265, :317-338)."""
+
+  def __init__(self, w, p, heads, dtype, dev):
+    g = lambda n: w[p + "/" + n]
+    c = g("dense1/kernel").shape[0]
+    self.c, self.heads = c, heads
+    self.s = c // heads
+    self.sp = L.padded_head(self.s)
+    sp = self.sp
+    self.gn = (L.vec(g("groupnorm/gamma"), dev), L.vec(g("groupnorm/beta"), dev))
+    self.proj_in = (L.dense_kernel(g("dense1/kernel"), dtype, dev), L.vec(g("dense1/bias"), dev))
+    self.proj_out = (L.dense_kernel(g("dense2/kernel"), dtype, dev), L.vec(g("dense2/bias"), dev))
+    a1, a2 = p + "/block/att_layer1", p + "/block/att_layer2"
+    self.qk1 = torch.cat([L.split_kernel(w[a1 + "/query/kernel"], sp, dtype, dev),
+                          L.split_kernel(w[a1 + "/key/kernel"], sp, dtype, dev)], 0).contiguous()
+    self.v1 = L.split_kernel(w[a1 + "/value/kernel"], sp, dtype, dev)
+    self.o1 = (L.merge_kernel(w[a1 + "/output/kernel"], sp, dtype, dev), L.vec(w[a1 + "/output/bias"], dev))
+    self.q2 = L.split_kernel(w[a2 + "/query/kernel"], sp, dtype, dev)
+    self.k2 = L.split_kernel(w[a2 + "/key/kernel"], sp, dtype, dev)
+    self.v2 = L.split_kernel(w[a2 + "/value/kernel"], sp, dtype, dev)
+    self.o2 = (L.merge_kernel(w[a2 + "/output/kernel"], sp, dtype, dev), L.vec(w[a2 + "/output/bias"], dev))
+    self.geglu = L.geglu_kernel(g("block/ffn/geglu/kernel"), g("block/ffn/geglu/bias"), dtype, dev)
+    self.ff_out = (L.dense_kernel(g("block/ffn/dense/kernel"), dtype, dev), L.vec(g("block/ffn/dense/bias"), dev))
+    self.ln = [(L.vec(g(f"block/layernorm{i}/gamma"), dev), L.vec(g(f"block/layernorm{i}/beta"), dev))
+               for i in (1, 2, 3)]
+    self.ctx_k = self.ctx_vt = None     # filled by UNet.set_context
+
+
+class UNet:
+  """Same kwargs as the reference constructor (unet.py:52-61).  Extra, build-only
+  kwargs: `weights` (reference-layout float32 dict, weights.unet_manifest names;
+  None = random init, the reference's behaviour when no checkpoint restores),
+  `dtype` (torch.float32 | torch.bfloat16 storage), `device`, `context_dim`."""
+
+  def __init__(self, model_channels=320, out_channels=4, num_blocks=2,
+               attention_resolutions=(4, 2, 1), dropout_rate=0.1, channel_mult=(1, 2, 4, 4),
+               num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
+               context_dim=1280, init="keras", seed=2):
+    self._model_channels = model_channels
+    self._out_channels = out_channels
+    self._num_blocks = num_blocks
+    self._attention_resolutions = attention_resolutions   # stored, never read (unet.py:66)
+    self._dropout_rate = dropout_rate                     # inference: dropout inactive
+    self._channel_mult = tuple(channel_mult)
+    self._num_heads = num_heads
+    self.dtype, self.device = dtype, torch.device(device)
+    self.manifest = unet_manifest(model_channels, out_channels, num_blocks, self._channel_mult,
+                                  num_heads, context_dim=context_dim)
+    if weights is None:
+      weights = init_weights(self.manifest, seed=seed, mode=init, scope="unet")
+    missing = [k for k in self.manifest if k not in weights]
+    if missing:
+      raise KeyError(f"UNet weights missing {len(missing)} tensors, e.g. {missing[:3]}")
+    self.buf = L.Buffers(self.device)
+    self._compile(weights)
+    self._ctx_key = None
+
+  # ---- build ---------------------------------------------------------------------
+  def _compile(self, w):
+    dt, dev, H = self.dtype, self.device, self._num_heads
+    mc = self._model_channels
+    self.conv_in = (L.vec(w["conv_in/kernel"], dev), L.vec(w["conv_in/bias"], dev))
+    self.time1 = (L.dense_kernel(w["time_dense1/kernel"], dt, dev), L.vec(w["time_dense1/bias"], dev))
+    self.time2 = (L.dense_kernel(w["time_dense2/kernel"], dt, dev), L.vec(w["time_dense2/bias"], dev))
+    res_all = []
+
+    def mk_res(p):
+      r = _Res(w, p, dt, dev)
+      res_all.append(r)
+      return r
+
+    def mk_st(p):
+      return _ST(w, p, H, dt, dev) if (p + "/dense1/kernel") in w else None
+
+    self.in_blocks, self.skip_ch, self.skip_lvl = [], [mc], [0]
+    lvl, i = 0, 0
+    while any(k.startswith(f"input_blocks/{i}/") for k in w):
+      p = f"input_blocks/{i}"
+      if (p + "/downsample/conv/kernel") in w:
+        k = w[p + "/downsample/conv/kernel"]
+        self.in_blocks.append(("down", L.conv_kernel(k, dt, dev), L.vec(w[p + "/downsample/conv/bias"], dev)))
+        lvl += 1
+        self.skip_ch.append(k.shape[3])
+      else:
+        r = mk_res(p + "/residual")
+        self.in_blocks.append(("res", r, mk_st(p + "/spatial_transformer")))
+        self.skip_ch.append(r.cout)
+      self.skip_lvl.append(lvl)
+      i += 1
+    self.mid = (mk_res("middle_block/residual1"), mk_st("middle_block/spatial_transformer"),
+                mk_res("middle_block/residual2"))
+    self.out_blocks = []
+    i = 0
+    while any(k.startswith(f"output_blocks/{i}/") for k in w):
+      p = f"output_blocks/{i}"
+      up = None
+      if (p + "/upsample/conv/kernel") in w:
+        up = (L.conv_kernel(w[p + "/upsample/conv/kernel"], dt, dev), L.vec(w[p + "/upsample/conv/bias"], dev))
+      self.out_blocks.append((mk_res(p + "/residual"), mk_st(p + "/spatial_transformer"), up))
+      i += 1
+    assert len(self.out_blocks) == len(self.skip_ch), "U-Net skip structure mismatch"
+    self.gn_out = (L.vec(w["groupnorm/gamma"], dev), L.vec(w["groupnorm/beta"], dev))
+    self.conv_out = (L.vec(w["conv_out/kernel"], dev), L.vec(w["conv_out/bias"], dev))
+    # all ResBlock temb projections as ONE skinny Dense [sum(Cout), 4*mc]
+    off, ks, bs = 0, [], []
+    for r in res_all:
+      r.temb_off = off
+      off += r.cout
+      ks.append(L.dense_kernel(r.temb_k, dt, dev))
+      bs.append(L.vec(r.temb_b, dev))
+      r.temb_k = r.temb_b = None
+    self.temb_all = (torch.cat(ks, 0).contiguous(), torch.cat(bs, 0).contiguous())
+    self.temb_total = off
+    self.sts = [b[2] for b in self.in_blocks if b[0] == "res" and b[2] is not None]
+    self.sts += [self.mid[1]] + [b[1] for b in self.out_blocks if b[1] is not None]
+
+  # ---- step-invariant cross-attention K / V ------------------------------------------
+  def set_context(self, context):
+    """Projects the text context through every cross-attention key/value layer once
+    (unet.py:274-275); valid until the next call with a different tensor."""
+    if context.dtype != self.dtype:
+      c2 = self.buf.get("ctx_cast", context.shape, self.dtype)
+      ops.cast(context, c2)
+      context = c2
+    R, Tk, _ = context.shape
+    tkp = (Tk + 7) // 8 * 8
+    for n, st in enumerate(self.sts):
+      hs = st.heads * st.sp
+      st.ctx_k = self.buf.get(f"ctxk{n}", (R, Tk, hs), self.dtype)
+      st.ctx_vt = self.buf.get(f"ctxv{n}", (R, hs, tkp), self.dtype, zero=True)
+      ops.linear(context, st.k2, st.ctx_k)
+      ops.bmm_nt(context, st.v2, st.ctx_vt, transposed_out=True)
+    self._ctx_rows = R
+
+  # ---- blocks ------------------------------------------------------------------------------
+  def _res(self, r, x, tall, out):
+    B_, dt = self.buf, self.dtype
+    R, h, w, _ = x.shape
+    t0 = B_.get("gn", (R, h, w, r.cin), dt)
+    ops.groupnorm(x, r.gn1[0], r.gn1[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
+    h1 = B_.get("h1", (R, h, w, r.cout), dt)
+    ops.conv3x3(t0, r.conv1[0], h1, bias=r.conv1[1], addend=tall[:, r.temb_off:r.temb_off + r.cout])
+    t1 = B_.get("gn", (R, h, w, r.cout), dt)
+    ops.groupnorm(h1, r.gn2[0], r.gn2[1], t1, GN_EPS_RES, silu=True, partial=self._gnp)
+    res = x
+    if r.shortcut is not None:
+      res = B_.get("sc", (R, h, w, r.cout), dt)
+      ops.linear(x, r.shortcut[0], res, bias=r.shortcut[1])
+    ops.conv3x3(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
+    return out
+
+  def _st(self, st, x, out):
+    B_, dt = self.buf, self.dtype
+    R, h, w, c = x.shape
+    T, hs = h * w, st.heads * st.sp
+    scale = st.s ** -0.5
+    t0 = B_.get("gn", (R, h, w, c), dt)
+    ops.groupnorm(x, st.gn[0], st.gn[1], t0, GN_EPS_ST, silu=False, partial=self._gnp)
+    ha = B_.get("st_a", (R, T, c), dt)
+    ops.linear(t0, st.proj_in[0], ha, bias=st.proj_in[1])
+    ln = B_.get("st_ln", (R, T, c), dt)
+    # self-attention (unet.py:309-310)
+    ops.layernorm(ha, st.ln[0][0], st.ln[0][1], ln, LN_EPS)
+    qk = B_.get("st_qk", (R, T, 2 * hs), dt)
+    ops.linear(ln, st.qk1, qk)
+    tp = (T + 7) // 8 * 8
+    vt = B_.get("st_vt", (R, hs, tp), dt, zero=True)
+    ops.bmm_nt(ln, st.v1, vt, transposed_out=True)
+    att = B_.get("st_att", (R, T, hs), dt)
+    ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale)
+    hb = B_.get("st_b", (R, T, c), dt)
+    ops.linear(att, st.o1[0], hb, bias=st.o1[1], residual=ha)
+    # cross-attention (unet.py:311-312)
+    ops.layernorm(hb, st.ln[1][0], st.ln[1][1], ln, LN_EPS)
+    q = B_.get("st_q", (R, T, hs), dt)
+    ops.linear(ln, st.q2, q)
+    ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale)
+    ops.linear(att, st.o2[0], ha, bias=st.o2[1], residual=hb)
+    # GEGLU feed-forward (unet.py:313, :323-325, :335-338)
+    ops.layernorm(ha, st.ln[2][0], st.ln[2][1], ln, LN_EPS)
+    ff = B_.get("st_ff", (R, T, 4 * c), dt)
+    ops.linear(ln, st.geglu[0], ff, bias=st.geglu[1], act=ops.ACT_GEGLU)
+    ops.linear(ff, st.ff_out[0], hb, bias=st.ff_out[1], residual=ha)
+    ops.linear(hb, st.proj_out[0], out, bias=st.proj_out[1], residual=x)
+    return out
+
+  # ---- forward ---------------------------------------------------------------------------------
+  def forward(self, x, t_rows=None, steps=None, index=None, out=None, shared_t=False):
+    """x f32 [R,h,w,4].  Timestep either per row (`t_rows` int32 [R]) or, for the
+    graph-replayed DDIM loop, `steps[*index]` for every row.  `shared_t=True` with
+    t_rows declares that all rows carry t_rows[0]."""
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    R, h, w, _ = x.shape
+    nlev = max(self.skip_lvl)
+    assert h % (1 << nlev) == 0 and w % (1 << nlev) == 0, "latent size must divide by 2**levels"
+    assert self.sts[0].ctx_k is not None and self._ctx_rows == R, "call set_context(context) first"
+    B_, dt, mc = self.buf, self.dtype, self._model_channels
+    f32 = torch.float32
+    self._gnp = B_.get("gn_partial", (R * 128 * 32 * 2,), f32)
+    # timestep embedding + MLP + all temb projections (unet.py:125-127, :386)
+    rt = 1 if (index is not None or shared_t) else R
+    emb = B_.get("temb_sin", (rt, mc), f32)
+    if index is not None:
+      ops.time_embedding(emb, mc, steps=steps, index=index)
+    else:
+      ops.time_embedding(emb, mc, t_rows=t_rows)
+    th = B_.get("temb_h", (rt, 4 * mc), f32)
+    ops.gemv(emb, self.time1[0], self.time1[1], th, act_out=ops.ACT_SILU)
+    temb = B_.get("temb", (rt, 4 * mc), f32)
+    ops.gemv(th, self.time2[0], self.time2[1], temb)
+    tall = B_.get("temb_all", (rt, self.temb_total), f32)
+    ops.gemv(temb, self.temb_all[0], self.temb_all[1], tall, act_in=ops.ACT_SILU)
+
+    n_in = len(self.in_blocks)
+    # cat[j]: input of output block j = [previous output | skip n_in - j]
+    prev_ch = [self.mid[2].cout] + [b[0].cout for b in self.out_blocks[:-1]]
+    cats = []
+    for j in range(len(self.out_blocks)):
+      i = n_in - j
+      lv = self.skip_lvl[i]
+      cats.append(B_.get(f"cat{j}", (R, h >> lv, w >> lv, prev_ch[j] + self.skip_ch[i]), dt))
+    skip_dst = lambda i: cats[n_in - i][..., prev_ch[n_in - i]:]
+
+    cur = skip_dst(0)
+    ops.conv3x3_small(x, self.conv_in[0], self.conv_in[1], cur)
+    for i, blk in enumerate(self.in_blocks):
+      dst = skip_dst(i + 1)
+      if blk[0] == "down":
+        ops.conv3x3(cur, blk[1], dst, bias=blk[2], stride=2)
+      else:
+        _, r, st = blk
+        if st is None:
+          self._res(r, cur, tall, dst)
+        else:
+          tmp = B_.get("blk_r", (R,) + tuple(dst.shape[1:3]) + (r.cout,), dt)
+          self._res(r, cur, tall, tmp)
+          self._st(st, tmp, dst)
+      cur = dst
+    r1, stm, r2 = self.mid
+    shp = (R,) + tuple(cur.shape[1:3]) + (r1.cout,)
+    m1 = self._res(r1, cur, tall, B_.get("blk_r", shp, dt))
+    m2 = self._st(stm, m1, B_.get("blk_s", shp, dt))
+    self._res(r2, m2, tall, cats[0][..., :r2.cout])
+    final = None
+    for j, (r, st, up) in enumerate(self.out_blocks):
+      xin = cats[j]
+      hh, ww = xin.shape[1], xin.shape[2]
+      last = j + 1 == len(self.out_blocks)
+      if last:
+        final = B_.get("final", (R, hh, ww, r.cout), dt)
+        dst = final
+      else:
+        dst = cats[j + 1][..., :r.cout]
+      stages = 1 + (st is not None) + (up is not None)
+      o = self._res(r, xin, tall, dst if stages == 1 else B_.get("blk_r", (R, hh, ww, r.cout), dt))
+      if st is not None:
+        stages_left = 1 if up is not None else 0
+        o = self._st(st, o, dst if stages_left == 0 else B_.get("blk_s", (R, hh, ww, r.cout), dt))
+      if up is not None:
+        ops.conv3x3(o, up[0], dst, bias=up[1], upsample=True)   # unet.py:44-47
+    t0 = B_.get("gn", tuple(final.shape), dt)
+    ops.groupnorm(final, self.gn_out[0], self.gn_out[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
+    if out is None:
+      out = torch.empty(R, h, w, self._out_channels, dtype=f32, device=self.device)
+    ops.conv3x3_small(t0, self.conv_out[0], self.conv_out[1], out)
+    return out
+
+  def __call__(self, inputs, time, context=None, y=None, training=False):
+    """unet.py:118 contract: inputs [R,h,w,4], time int [R], context [R,T,D]."""
+    if training:
+      raise NotImplementedError("the HIP path is inference only")
+    x = torch.as_tensor(inputs, dtype=torch.float32).to(self.device).contiguous()
+    t = torch.as_tensor(time).to(torch.int32).to(self.device).contiguous()
+    if context is not None:
+      ctx = torch.as_tensor(context).to(self.device)
+      key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
+      if key != self._ctx_key:
+        self.set_context(ctx.contiguous())
+        self._ctx_key = key
+    return self.forward(x, t_rows=t)

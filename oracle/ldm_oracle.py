@@ -136,7 +136,7 @@ def multihead_attention(query, context, w, scale_dim):
   k = projection_split(context, w("key/kernel"))
   v = projection_split(context, w("value/kernel"))
   logits = torch.einsum("nqhs,nchs->nhqc", q, k)
-  logits = logits * (scale_dim ** -0.5)
+  logits = logits * (q.shape[-1] ** -0.5)   # size_per_head == the kernel's S axis
   p = torch.softmax(logits, dim=3)
   o = torch.einsum("nhqc,nchs->nqhs", p, v)
   return projection_merge(o, w("output/kernel"), w("output/bias"))
