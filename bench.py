@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of latent-diffusion sampling on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full pass of the hot path over one batch: text-encode -> 200 DDIM
+steps (each one U-Net forward on 2B rows + CFG/DDIM update) -> KL decode (+ one RCCL
+all-gather of the decoded images when N > 1).  Workload = BASELINE.json configs[2]
+(the configuration the metric is quoted on): txt2img-f8 1.45B, B=16 per GPU, latent
+32x32x4, 200 DDIM steps, CFG 5, bf16 U-Net / text encoder / decoder with the f32
+scheduler; random-init weights, synthetic x_T and random BERT token ids (no network:
+no checkpoints, no datasets).  Weak scaling: every GPU samples its own 16 images.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  roofline     : the MFMA GEMM/implicit-conv kernel family (dominant kernel):
+                 algorithmic FLOPs per U-Net step in that family / its summed launch
+                 time per step, measured with HIP events around every launch on the
+                 launch stream in one instrumented (non-graph) step after the timed region.
+  cpu_baseline : the CPU oracle (a port of the reference arithmetic; TensorFlow is not
+                 installable here) timed on the host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic work (SURVEY.md section 8d / BASELINE.md section 2), GFLOP per U-Net row @32x32
+GF_UNET_ROW = {32: 182.48, 64: 809.54}
+GF_CONV_ROW = {32: 100.1}
+GF_GEMM_ROW = {32: 73.5}
+GF_CTX_KV_ROW = 4.9          # cross-attention K/V GEMMs, hoisted out of the step (step-invariant)
+GF_DECODE = {32: 623.11, 64: 2518.3}
+GF_TEXT_ROW = 77.96
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
+
+FULL = dict(
+    cond_stage_model=dict(vocab_size=30522, encoder_stack_size=32, hidden_size=1280, num_heads=8,
+                          size_per_head=64, max_seq_len=77, filter_size=5120, dropout_rate=0.1),
+    autoencoder_kl=dict(latent_channels=4, channels=128, num_blocks=2, attention_resolutions=[],
+                        dropout_rate=0., multipliers=[1, 2, 4, 4], resample_with_conv=True),
+    unet=dict(model_channels=320, out_channels=4, num_blocks=2, attention_resolutions=[4, 2, 1],
+              dropout_rate=0.1, channel_mult=[1, 2, 4, 4], num_heads=8),
+    ldm=dict(num_steps=1000, beta_start=0.00085, beta_end=0.012, v_posterior=0., scale_factor=0.18215,
+             eta=0., num_ddim_steps=200),
+)
+
+
+def synthetic_token_ids(batch, seed=1, vocab=30522, T=77):
+  """uncond rows = [CLS][SEP][PAD]...; cond rows = uniform random ids."""
+  uncond = np.array([[101, 102] + [0] * (T - 2)], dtype=np.int64)
+  cond = np.random.default_rng(seed).integers(0, vocab, size=(1, T), dtype=np.int64)
+  return np.concatenate([np.tile(uncond, (batch, 1)), np.tile(cond, (batch, 1))], 0)
+
+
+def log(rank, *a):
+  if rank == 0:
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(weights, latent, n_ddim):
+  """CPU oracle on a bounded sample: ONE U-Net evaluation of the CFG pair of one image
+  (2 rows), ONE text encoding of its 2 rows and ONE decode, extrapolated to
+  n_ddim U-Net evaluations per image.  Test infrastructure used as the checker's
+  clock only -- never part of the measured GPU path."""
+  from oracle import ldm_oracle as O
+  cores = os.cpu_count() or 1
+  torch.set_num_threads(cores)
+  g = np.random.default_rng(0)
+  ids = synthetic_token_ids(1)
+  x = g.standard_normal((2, latent, latent, 4)).astype(np.float32)
+  with torch.no_grad():
+    t0 = time.perf_counter()
+    ctx = O.text_encoder(ids, weights["cond_stage_model"])
+    t_text = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.unet_forward(x, np.array([981, 981], dtype=np.int32), ctx, weights["unet"])
+    t_unet = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.decoder_forward(torch.from_numpy(x[:1]), weights["autoencoder"])
+    t_dec = time.perf_counter() - t0
+  per_image = n_ddim * t_unet + t_dec + t_text
+  return {
+      "value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+      "sample": (f"torch-CPU f32 oracle, {cores} threads: 1 U-Net eval of one image's CFG pair "
+                 f"[2,{latent},{latent},4] = {t_unet:.2f}s, text-encode 2 rows = {t_text:.2f}s, "
+                 f"KL decode 1 image = {t_dec:.2f}s; images/s = 1/({n_ddim}*unet + decode + text)"),
+      "ms_per_unet_step": t_unet * 1e3,
+  }
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=2)
+  ap.add_argument("--warmup", type=int, default=1)
+  ap.add_argument("--batch-per-gpu", type=int, default=16)
+  ap.add_argument("--ddim-steps", type=int, default=200)
+  ap.add_argument("--latent", type=int, default=32)
+  ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+  ap.add_argument("--guidance", type=float, default=5.0)
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--no-graph", action="store_true")
+  args = ap.parse_args()
+
+  from ldm_tf2_amd import distributed as D
+  rank, world, local = D.init_from_env()
+  if world != args.gpus:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs an MI355X: the sampling path has no CPU fallback")
+  torch.cuda.set_device(local)
+  dev = torch.device("cuda", local)
+  dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+  from ldm_tf2_amd import ops, weights as Wt
+  from ldm_tf2_amd.autoencoder import AutoencoderKL
+  from ldm_tf2_amd.model_runners import LatentDiffusionModelSampler
+  from ldm_tf2_amd.transformer import TransformerModel
+  from ldm_tf2_amd.unet import UNet
+
+  t_build = time.perf_counter()
+  cfg = FULL
+  w = {
+      "unet": Wt.init_weights(Wt.unet_manifest(**cfg["unet"]), seed=2, scope="unet"),
+      "cond_stage_model": Wt.init_weights(Wt.transformer_manifest(**cfg["cond_stage_model"]), seed=2,
+                                          scope="cond_stage_model"),
+      "autoencoder": Wt.init_weights(Wt.decoder_manifest(**cfg["autoencoder_kl"]), seed=2,
+                                     scope="autoencoder"),
+  }
+  log(rank, f"weights generated in {time.perf_counter() - t_build:.1f}s")
+  unet = UNet(**cfg["unet"], weights=w["unet"], dtype=dtype, device=dev)
+  txt = TransformerModel(**cfg["cond_stage_model"], weights=w["cond_stage_model"], dtype=dtype, device=dev)
+  ae = AutoencoderKL(**cfg["autoencoder_kl"], weights=w["autoencoder"], dtype=dtype, device=dev)
+  ldm = dict(cfg["ldm"], num_ddim_steps=args.ddim_steps)
+  sampler = LatentDiffusionModelSampler(unet, ae, txt, use_graph=not args.no_graph, verbose=False, **ldm)
+  keep_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+  if not keep_cpu:
+    w = None
+  log(rank, f"models on device in {time.perf_counter() - t_build:.1f}s")
+
+  B = args.batch_per_gpu
+  shape = [B, args.latent, args.latent, 4]
+  ids = synthetic_token_ids(B)
+  first, _ = D.shard_range(rank, B)
+
+  def one_pass():
+    images = sampler.ddim_p_sample_loop(ids, shape, guidance_scale=args.guidance, seed=0,
+                                        first_sample_index=first)
+    return D.all_gather_images(images)
+
+  for _ in range(args.warmup):
+    one_pass()
+  D.barrier()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  loop_ms = []
+  for _ in range(args.steps):
+    out = one_pass()
+    loop_ms.append(sampler._loop_events)
+  D.barrier()
+  torch.cuda.synchronize()
+  elapsed = time.perf_counter() - t0
+  elapsed = D.max_over_ranks(elapsed, dev)
+  ms_unet_step = float(np.mean([a.elapsed_time(b) / n for a, b, n in loop_ms]))
+  assert tuple(out.shape) == (world * B, 8 * args.latent, 8 * args.latent, 3)
+  assert bool(torch.isfinite(out).all()), "non-finite images"
+
+  # ---- instrumented step: HIP events around every MFMA GEMM/conv launch --------------
+  R = 2 * B
+  timers = []
+  ops.set_gemm_timer(timers)
+  sampler._index_dev.fill_(args.ddim_steps - 1)
+  sampler._step(args.guidance, False, None, dec_index=False)
+  torch.cuda.synchronize()
+  ops.set_gemm_timer(None)
+  gemm_ms = sum(a.elapsed_time(b) for a, b in timers)
+  lat = args.latent
+  gf_family = (GF_CONV_ROW.get(lat, 0) + GF_GEMM_ROW.get(lat, 0) - GF_CTX_KV_ROW) * R if lat in GF_CONV_ROW else None
+  roofline = None
+  if gf_family:
+    achieved = gf_family / gemm_ms          # GFLOP / ms = TFLOP/s
+    peak = PEAK_TFLOPS[args.dtype]
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
+                "kernel": "gemm_kernel<T,BM,BN,WM,WN> (Dense/1x1/projection GEMMs + implicit-GEMM 3x3 convs)",
+                "launches_per_unet_step": len(timers), "ms_per_unet_step_in_kernel": gemm_ms,
+                "algorithmic_gflop_per_unet_step": gf_family}
+
+  if rank == 0:
+    total_images = world * B * args.steps
+    value = total_images / elapsed
+    res = {
+        "metric": "images/sec (256x256, 200 DDIM steps, CFG=5)" if (lat == 32 and args.ddim_steps == 200)
+                  else f"images/sec ({8 * lat}x{8 * lat}, {args.ddim_steps} DDIM steps, CFG={args.guidance:g})",
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": (f"txt2img-f8 1.45B LDM (BASELINE configs[2]): B={B}/GPU, latent {lat}x{lat}x4, "
+                                f"{args.ddim_steps} DDIM steps, CFG {args.guidance:g}, {args.dtype} U-Net/text/decoder, "
+                                "f32 scheduler, random-init weights, synthetic x_T + random BERT ids"),
+                   "batch_per_gpu": B, "global_batch": world * B, "ddim_steps": args.ddim_steps,
+                   "latent": [lat, lat, 4], "parallelism": f"replicas x{world}, one all-gather of images"},
+        "ms_per_unet_step": ms_unet_step,
+        "unet_tflops": GF_UNET_ROW.get(lat, 0) * R / ms_unet_step if lat in GF_UNET_ROW else None,
+        "hip_graph": not args.no_graph,
+        "roofline": roofline,
+    }
+    if keep_cpu:
+      log(rank, "timing the CPU oracle (bounded sample)...")
+      res["cpu_baseline"] = cpu_baseline(w, lat, args.ddim_steps)
+    else:
+      res["cpu_baseline"] = None
+    print(json.dumps(res), flush=True)
+  D.barrier()
+
+
+if __name__ == "__main__":
+  main()

@@ -78,11 +78,29 @@ def workspace(device):
   return ws
 
 
+_GEMM_TIMER = None
+
+
+def set_gemm_timer(sink):
+  """Measurement hook (bench.py): while `sink` is a list, every ldm_gemm launch is
+  bracketed by HIP events recorded on the launch stream and (start, end) is
+  appended to it.  None switches it off."""
+  global _GEMM_TIMER
+  _GEMM_TIMER = sink
+
+
 def _gemm(p: GemmParams, device):
   ws = workspace(device)
   p.workspace = ws.data_ptr()
   p.workspace_bytes = ws.numel()
+  if _GEMM_TIMER is None:
+    check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
+    return
+  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+  e0.record()
   check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
+  e1.record()
+  _GEMM_TIMER.append((e0, e1))
 
 
 def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_rows=0,

@@ -1,0 +1,99 @@
+"""Sampler harness: YAML -> three models -> prompt tokens -> DDIM loop -> images.npy.
+
+Same I/O contract as the reference CLI (run_ldm_sampler.py:49-99): reads the YAML
+sections `ldm_sampling`, `pre_ckpt_paths`, `cond_stage_model`, `autoencoder_kl|vq`,
+`unet`, `ldm` (keys == constructor kwargs), tiles the prompt into ids
+[uncond x B; cond x B], samples, converts with the per-image min-max rule
+(:18-25) and writes uint8 NHWC `images.npy`.
+
+    python -m ldm_tf2_amd.run_ldm_sampler --config_path all_in_one_config.yaml \
+        [--dtype bf16|f32] [--seed 0] [--out images.npy]
+
+Checkpoints: the reference restores TF checkpoints with expect_partial(), which
+silently leaves random-init weights when nothing matches.
+TF checkpoints cannot be read here; `pre_ckpt_paths` entries that point at an
+`.npz` of reference-layout arrays (weights.py names) are loaded, anything else
+falls back to seeded random init with a warning -- the same observable behaviour.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+from . import ops
+from .autoencoder import AutoencoderKL, AutoencoderVQ
+from .model_runners import LatentDiffusionModelSampler
+from .tokenizer import get_token_ids
+from .transformer import TransformerModel
+from .unet import UNet
+
+
+def tensor_to_image(images):
+  """run_ldm_sampler.py:18-25 on the device: per image (x-min)/(max-min)*255 ->
+  uint8 (truncation).  Returns a NumPy uint8 array."""
+  x = images.contiguous()
+  out = torch.empty(tuple(x.shape), dtype=torch.uint8, device=x.device)
+  ops.minmax_u8(x, out)
+  return out.cpu().numpy()
+
+
+def _load_weights(path, what):
+  if path and os.path.isfile(path) and path.endswith(".npz"):
+    return dict(np.load(path))
+  print(f"[WARN] no loadable checkpoint for {what} at {path!r}: using random-init weights "
+        "(the reference's expect_partial() behaviour)", file=sys.stderr)
+  return None
+
+
+def build_from_config(config, dtype=torch.bfloat16, device="cuda:0", seed=2, use_graph=True,
+                      verbose=True):
+  ck = config.get("pre_ckpt_paths", {})
+  transformer = TransformerModel(**config["cond_stage_model"], dtype=dtype, device=device, seed=seed,
+                                 weights=_load_weights(ck.get("cond_stage_model"), "cond_stage_model"))
+  unet = UNet(**config["unet"], dtype=dtype, device=device, seed=seed,
+              context_dim=config["cond_stage_model"]["hidden_size"],
+              weights=_load_weights(ck.get("unet"), "unet"))
+  kind = config["ldm_sampling"]["autoencoder_type"]
+  if kind == "kl":
+    autoencoder = AutoencoderKL(**config["autoencoder_kl"], dtype=dtype, device=device, seed=seed,
+                                weights=_load_weights(ck.get("autoencoder"), "autoencoder"))
+  elif kind == "vq":
+    autoencoder = AutoencoderVQ(**config["autoencoder_vq"], dtype=dtype, device=device, seed=seed,
+                                latent_size=config["ldm_sampling"]["latent_shape"][1],
+                                weights=_load_weights(ck.get("autoencoder"), "autoencoder"))
+  else:
+    raise NotImplementedError("invalid autoencoder type.")
+  return LatentDiffusionModelSampler(unet=unet, autoencoder=autoencoder, cond_stage_model=transformer,
+                                     use_graph=use_graph, verbose=verbose, **config["ldm"])
+
+
+def main(argv=None):
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--config_path", required=True)
+  ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+  ap.add_argument("--seed", type=int, default=0, help="seed of x_T (and of the noise when eta > 0)")
+  ap.add_argument("--out", default="images.npy")
+  args = ap.parse_args(argv)
+  with open(args.config_path) as f:
+    config = yaml.safe_load(f)
+  dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+  sampler = build_from_config(config, dtype=dtype)
+  samp = config["ldm_sampling"]
+  if samp.get("sample_save_progress"):
+    raise NotImplementedError("progressive sampling is not on the hot path (the reference's "
+                              "implementation of it cannot run: SURVEY.md section 2 row 1b)")
+  token_ids = get_token_ids(samp["text_prompt"], samp["latent_shape"][0], samp["vocab_dir"],
+                            config["cond_stage_model"]["max_seq_len"])
+  images = sampler.ddim_p_sample_loop(token_ids, samp["latent_shape"], samp["guidance_scale"],
+                                      seed=args.seed)
+  print(f"[INFO] Save generated images to '{args.out}'...")
+  np.save(args.out, tensor_to_image(images))
+
+
+if __name__ == "__main__":
+  main()

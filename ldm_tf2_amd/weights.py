@@ -266,10 +266,10 @@ def init_weights(manifest, seed=2, mode="keras", scope=""):
     rng = np.random.default_rng([int(seed), key])
     if kind in ("kernel", "codebook"):
       fi, fo = _fans(shape)
-      lim = np.sqrt(6.0 / (fi + fo))
-      a = rng.uniform(-lim, lim, size=shape)
+      lim = np.float32(np.sqrt(6.0 / (fi + fo)))
+      a = (rng.random(size=shape, dtype=np.float32) * np.float32(2.0) - np.float32(1.0)) * lim
     elif kind == "embedding":
-      a = rng.uniform(-0.05, 0.05, size=shape)
+      a = (rng.random(size=shape, dtype=np.float32) * np.float32(2.0) - np.float32(1.0)) * np.float32(0.05)
     elif kind == "bias":
       a = np.zeros(shape) if mode == "keras" else rng.uniform(-0.1, 0.1, size=shape)
     elif kind == "gamma":

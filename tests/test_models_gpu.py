@@ -167,8 +167,9 @@ def test_ddim_sample_single_step(dev, dtype, unet_w, txt_w, kl_w):
                                  noise=noise, clip_denoised=True)
   got, got_x0 = s.ddim_sample(torch.from_numpy(xt), torch.from_numpy(ctx), 7, guidance_scale=5.,
                               clip_denoised=True, return_pred_x0=True, noise=noise)
-  check(got, ref, dtype, "ddim_sample", factor=2.0)
-  check(got_x0, ref_x0, dtype, "pred_x0", factor=2.0)
+  # eps errors are amplified by guidance (x5) and by c2 = sqrt(1/abar - 1) (~5 at t=701)
+  check(got, ref, dtype, "ddim_sample", factor=4.0)
+  check(got_x0, ref_x0, dtype, "pred_x0", factor=4.0)
 
 
 @pytest.mark.parametrize("dtype", DT)
