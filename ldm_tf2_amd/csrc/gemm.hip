@@ -12,14 +12,26 @@
 //     f32 : v_mfma_f32_32x32x2_f32 issued 4x per 16-byte fragment; lane half h
 //     then covers k = 4h..4h+3 of each 8-wide k group for A and B alike, a
 //     permutation of the summation order only.
-//   * global -> register -> LDS staging, double-buffered: the loads of K-tile
-//     t+1 are in flight while tile t is multiplied; one barrier per K-tile.
+//   * staging is branch-free and asynchronous: every 16-byte piece is a
+//     `buffer_load_dwordx4 ... lds` (LDS-DMA, no VGPR round trip) whose offset is
+//     pushed out of range when the piece is padding (image border, M/N/K tails)
+//     -- the hardware range check then writes zeros, so the conv's zero padding
+//     costs one v_cndmask per piece and no divergent control flow.  An LDS-DMA
+//     wave-instruction writes 64 x 16 B linearly, so the XOR swizzle is applied
+//     to the SOURCE chunk each lane fetches.  Three LDS stages form a ring: tile
+//     t+2 is issued while tile t is multiplied; a counted s_waitcnt vmcnt(N)
+//     (never 0 in the loop) plus ONE raw s_barrier per K-tile orders it.
+//   * the epilogue goes through LDS: accumulators are dropped as an f32 tile and
+//     re-read row-wise so that bias / addend / residual / output all move as
+//     16-byte vectors (the MFMA accumulator layout alone would give 2-byte
+//     scattered stores).
 //   * workgroup ids are remapped so that the tiles sharing an A row-panel run
 //     on one XCD (its L2 then serves the panel's re-reads).
 //   * small-M layers (4x4 / 8x8 feature maps) stream their weights with split-K
 //     over all CUs; partial sums go to an f32 workspace and a second kernel
 //     reduces + applies the epilogue.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,14 +46,19 @@ struct GemmArgs {
   int64_t lda, ldr, ldc_m, ldc_n;
   int64_t stride_a, stride_w, stride_c, stride_r;
   int64_t add_ld;
+  uint32_t a_bytes, w_bytes;   // addressable extent from the (per-batch) base pointers
   int M, N, K, batch;
   int add_rows;
   int conv, H, W, Cin, OH, OW, stride, upsample;
   int act, out_dtype;
   int split_k, ktiles_per_split, ktiles;
   int tiles_m, tiles_n;
+  int vec_epilogue;
+  int debug;   // ablation switches (LDM_GEMM_DEBUG env): 1 = no in-loop loads, 2 = no MFMA, 4 = no barrier
   float alpha;
 };
+
+constexpr uint32_t kOOB = 0x80000000u;   // >= any num_records we accept: load returns 0
 
 __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& b, bf16_t) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
@@ -54,7 +71,7 @@ __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& 
                                                0, 0, 0);
 }
 
-// value before activation: alpha*acc + bias[n] + addend[group(m)][n]
+// value before activation: acc(already * alpha) + bias[n] + addend[group(m)][n]
 __device__ __forceinline__ float epi_pre(const GemmArgs& p, int m, int n, float acc) {
   float v = acc * p.alpha;
   if (p.bias) v += p.bias[n];
@@ -83,22 +100,30 @@ __device__ __forceinline__ float apply_act(int act, float v) {
 
 template <typename T, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
-  constexpr int NT = WM * WN * 64;
+  // The body uses LDS address-space pointers and gfx950 inline asm, which only the
+  // device pass can parse; the host pass just needs the launch stub.
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int CA = BM * 8 / NT, CB = BN * 8 / NT;
-  constexpr int EPC = 16 / (int)sizeof(T);
+  constexpr int LA = BM / (8 * NW), LB = BN / (8 * NW);   // LDS-DMA instructions per wave per tile
+  constexpr int NL = LA + LB;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int EPC = 16 / ES;
   constexpr int BKE = 8 * EPC;
-  constexpr int RSTEP = NT / 8;  // rows covered per staging pass
-  static_assert(CA >= 1 && CB >= 1 && TM >= 1 && TN >= 1, "tile");
+  constexpr int NSTAGE = 3;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int SMEM = NSTAGE * STAGE;
+  static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile");
+  static_assert(BM * BN * 4 <= SMEM, "epilogue tile must fit the staging LDS");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
 
-  __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
-  char* sA = smem;
-  char* sB = smem + 2 * BM * 128;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
   // ---- block -> (tile_m, tile_n, split, batch), XCD-aware -------------------
@@ -118,80 +143,106 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
 
   const int kt_begin = split * p.ktiles_per_split;
   const int kt_end = min(p.ktiles, kt_begin + p.ktiles_per_split);
+  const int nk = kt_end - kt_begin;
 
-  const T* A = (const T*)p.a + (int64_t)bz * p.stride_a;
-  const T* Wt = (const T*)p.w + (int64_t)bz * p.stride_w;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.a) + (int64_t)bz * p.stride_a * ES, 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(p.w) + (int64_t)bz * p.stride_w * ES, 0, p.w_bytes, 0x00020000);
 
-  // ---- per-thread staging geometry ------------------------------------------
-  const int ck = tid & 7;
-  const int srow = tid >> 3;
-  int a_pix[CA], a_iy[CA], a_ix[CA];
+  // ---- per-lane staging geometry ---------------------------------------------
+  // LDS-DMA instruction i of this wave fills rows g*8 .. g*8+7 (g = i*NW + wave) of the
+  // tile: lane l lands at row g*8 + (l>>3), 16-byte slot l&7, so it must FETCH chunk
+  // (l&7) ^ ((row>>1)&7) of that row (the read side applies the same XOR).
+  // conv: a_base = byte offset of pixel (b, oy*s-1, ox*s-1) (+ chunk), a_mask = 9 tap-valid bits
+  //       upsample: a_base = byte offset of image b, a_aux = ((oy-1) << 16) | ((ox-1) & 0xffff)
+  // gemm: a_base = byte offset of row m (+ chunk), a_mask = row valid
+  int a_base[LA], a_mask[LA], a_aux[LA], a_kc[LA];
 #pragma unroll
-  for (int i = 0; i < CA; ++i) {
-    const int m = m0 + srow + i * RSTEP;
-    if (p.conv) {
-      if (m < p.M) {
+  for (int i = 0; i < LA; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int ck = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    a_base[i] = 0; a_mask[i] = 0; a_aux[i] = 0; a_kc[i] = ck * EPC;
+    if (m < p.M) {
+      if (p.conv) {
         const int ohw = p.OH * p.OW;
         const int b = m / ohw, rem = m - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        a_pix[i] = b * p.H * p.W;
-        a_iy[i] = oy * p.stride - 1;
-        a_ix[i] = ox * p.stride - 1;
+        const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
+        const int Hs = p.upsample ? p.H * 2 : p.H, Ws = p.upsample ? p.W * 2 : p.W;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+          if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) mask |= 1 << t;
+        }
+        a_mask[i] = mask;
+        if (p.upsample) {
+          a_base[i] = (int)((int64_t)b * p.H * p.W * p.lda * ES) + ck * 16;
+          a_aux[i] = (iy0 << 16) | (ix0 & 0xffff);
+        } else {
+          a_base[i] = (int)(((int64_t)(b * p.H + iy0) * p.W + ix0) * p.lda * ES) + ck * 16;
+        }
       } else {
-        a_pix[i] = 0; a_iy[i] = -(1 << 20); a_ix[i] = 0;
+        a_base[i] = (int)((int64_t)m * p.lda * ES) + ck * 16;
+        a_mask[i] = 1;
       }
-    } else {
-      a_pix[i] = m < p.M ? m : -1;
-      a_iy[i] = 0; a_ix[i] = 0;
     }
   }
-  const int Hs = p.upsample ? p.H * 2 : p.H, Ws = p.upsample ? p.W * 2 : p.W;
-
-  u32x4 ra[CA], rb[CB];
-  auto load_tile = [&](int kt) {
-    const int k0 = kt * BKE;
-    const int kc = k0 + ck * EPC;
-    if (p.conv) {
-      const int tap = k0 / p.Cin;
-      const int ci = k0 - tap * p.Cin + ck * EPC;
-      const int kh = tap / 3, kw = tap - kh * 3;
+  int b_base[LB], b_kc[LB];
 #pragma unroll
-      for (int i = 0; i < CA; ++i) {
-        int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
-        const bool ok = (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws;
-        if (p.upsample) { iy >>= 1; ix >>= 1; }
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) v = *(const u32x4*)(A + (int64_t)(a_pix[i] + iy * p.W + ix) * p.lda + ci);
-        ra[i] = v;
+  for (int i = 0; i < LB; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int ck = (lane & 7) ^ ((row >> 1) & 7);
+    const int n = n0 + row;
+    b_kc[i] = ck * EPC;
+    b_base[i] = n < p.N ? (int)((int64_t)n * p.K * ES) + ck * 16 : -1;
+  }
+  const int row_pitch = (int)(p.lda * ES);          // bytes per pixel
+  const int line_pitch = p.W * row_pitch;           // bytes per image line
+
+  auto issue_tile = [&](int kt, int stage) {
+    char* dA = smem + stage * STAGE + wave * 1024;
+    char* dB = smem + stage * STAGE + BM * 128 + wave * 1024;
+    const int k0 = kt * BKE;
+    if (p.conv) {
+      const int tap = k0 / p.Cin;                    // scalar
+      const int cib = (k0 - tap * p.Cin) * ES;       // channel byte offset
+      const int kh = tap / 3, kw = tap - kh * 3;
+      if (p.upsample) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+          const int iy = ((a_aux[i] >> 16) + kh) >> 1;
+          const int ix = ((int)(short)(a_aux[i] & 0xffff) + kw) >> 1;
+          const uint32_t off = (uint32_t)(a_base[i] + iy * line_pitch + ix * row_pitch + cib);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dA + i * NW * 1024), 16,
+                                                   ((a_mask[i] >> tap) & 1) ? off : kOOB, 0, 0, 0);
+        }
+      } else {
+        const int toff = kh * line_pitch + kw * row_pitch + cib;   // scalar
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+          const uint32_t off = (uint32_t)(a_base[i] + toff);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dA + i * NW * 1024), 16,
+                                                   ((a_mask[i] >> tap) & 1) ? off : kOOB, 0, 0, 0);
+        }
       }
     } else {
+      const int kb = k0 * ES;
 #pragma unroll
-      for (int i = 0; i < CA; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (a_pix[i] >= 0 && kc < p.K) v = *(const u32x4*)(A + (int64_t)a_pix[i] * p.lda + kc);
-        ra[i] = v;
+      for (int i = 0; i < LA; ++i) {
+        const uint32_t off = (uint32_t)(a_base[i] + kb);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dA + i * NW * 1024), 16,
+                                                 (a_mask[i] && (k0 + a_kc[i]) < p.K) ? off : kOOB, 0, 0, 0);
       }
     }
+    const int kb = k0 * ES;
 #pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      const int n = n0 + srow + i * RSTEP;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (n < p.N && kc < p.K) v = *(const u32x4*)(Wt + (int64_t)n * p.K + kc);
-      rb[i] = v;
-    }
-  };
-  auto store_tile = [&](int buf) {
-    char* dA = sA + buf * (BM * 128);
-    char* dB = sB + buf * (BN * 128);
-#pragma unroll
-    for (int i = 0; i < CA; ++i) {
-      const int row = srow + i * RSTEP;
-      *(u32x4*)(dA + row * 128 + ((ck ^ ((row >> 1) & 7)) << 4)) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < CB; ++i) {
-      const int row = srow + i * RSTEP;
-      *(u32x4*)(dB + row * 128 + ((ck ^ ((row >> 1) & 7)) << 4)) = rb[i];
+    for (int i = 0; i < LB; ++i) {
+      const uint32_t off = (uint32_t)(b_base[i] + kb);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dB + i * NW * 1024), 16,
+                                               (b_base[i] >= 0 && (k0 + b_kc[i]) < p.K) ? off : kOOB, 0, 0, 0);
     }
   };
 
@@ -206,34 +257,43 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   const int lr = lane & 31, lh = lane >> 5;
   const int sw = (lr >> 1) & 7;
   const int offA = (wm * WTM + lr) * 128;
-  const int offB = (wn * WTN + lr) * 128;
+  const int offB = BM * 128 + (wn * WTN + lr) * 128;
 
-  if (kt_begin < kt_end) {
-    load_tile(kt_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) load_tile(kt + 1);
-    const char* cA = sA + buf * (BM * 128) + offA;
-    const char* cB = sB + buf * (BN * 128) + offB;
+  if (nk > 0) issue_tile(kt_begin, 0);
+  if (nk > 1) issue_tile(kt_begin + 1, 1);
+  int st_cur = 0, st_nxt = 2;     // stage of tile t / stage tile t+2 goes to
+  for (int t = 0; t < nk; ++t) {
+    // tile t has landed once at most the NL loads of tile t+1 are still outstanding
+    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's pieces of tile t landed; everyone left tile t-1
+    if (t + 2 < nk) issue_tile(kt_begin + t + 2, st_nxt);
+    const char* cA = smem + st_cur * STAGE + offA;
+    const char* cB = smem + st_cur * STAGE + offB;
+    // all fragment reads of the K-tile are issued up front (the LDS pipe stays full and
+    // only the first MFMA waits a full LDS latency); the MFMAs then drain them in order
+    u32x4 fa[4][TM], fb[4][TN];
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       const int coff = ((kg * 2 + lh) ^ sw) << 4;
-      u32x4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *(const u32x4*)(cA + i * 32 * 128 + coff);
+      for (int i = 0; i < TM; ++i) fa[kg][i] = *(const u32x4*)(cA + i * 32 * 128 + coff);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *(const u32x4*)(cB + j * 32 * 128 + coff);
+      for (int j = 0; j < TN; ++j) fb[kg][j] = *(const u32x4*)(cB + j * 32 * 128 + coff);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[i], fb[j], T());
-    }
-    if (kt + 1 < kt_end) store_tile(buf ^ 1);
-    __syncthreads();
+        for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[kg][i], fb[kg][j], T());
+    __builtin_amdgcn_s_setprio(0);
+    st_cur = st_cur == NSTAGE - 1 ? 0 : st_cur + 1;
+    st_nxt = st_nxt == NSTAGE - 1 ? 0 : st_nxt + 1;
   }
+  __syncthreads();   // all waves done with the staging LDS before the epilogue reuses it
 
   // ---- epilogue ---------------------------------------------------------------
   const int mb = m0 + wm * WTM + 4 * lh;
@@ -254,6 +314,102 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
       }
     return;
   }
+
+  if (p.vec_epilogue) {
+    // (1) accumulators -> f32 tile [BM][BN] in LDS (the staging buffers are dead: the
+    //     K loop's last barrier has been passed by every wave)
+    float* sC = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          sC[row * BN + wn * WTN + j * 32 + lr] = acc[i][j][r] * p.alpha;
+        }
+    __syncthreads();
+    // (2) row-wise pieces of 8 output columns per thread
+    const bool geglu = p.act == LDM_ACT_GEGLU;
+    constexpr int PCOLS = BN / 8;                 // pieces per tile row (plain)
+    const int pcols = geglu ? PCOLS / 2 : PCOLS;
+    const int npieces = BM * pcols;
+    const int nout = geglu ? p.N / 2 : p.N;
+    for (int c = tid; c < npieces; c += NT) {
+      const int row = c / pcols, pc = c - row * pcols;
+      const int m = m0 + row;
+      int ncol, lcol;                             // first output column, first LDS column (value)
+      if (geglu) {
+        const int oc = pc * 8;                    // within the tile's BN/2 output columns
+        lcol = (oc >> 5) * 64 + (oc & 31);
+        ncol = (n0 >> 1) + oc;
+      } else {
+        lcol = pc * 8;
+        ncol = n0 + lcol;
+      }
+      if (m >= p.M || ncol >= nout) continue;
+      float v[8];
+      {
+        const f32x4 x0 = *(const f32x4*)(sC + row * BN + lcol);
+        const f32x4 x1 = *(const f32x4*)(sC + row * BN + lcol + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = x0[e]; v[4 + e] = x1[e]; }
+      }
+      const int nlog = geglu ? n0 + lcol : ncol;  // logical (pre-GEGLU) column of v[0]
+      if (p.bias) {
+        const f32x4 b0 = *(const f32x4*)(p.bias + nlog), b1 = *(const f32x4*)(p.bias + nlog + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+      }
+      if (p.addend) {
+        const float* ad = p.addend + (int64_t)(m / p.add_rows) * p.add_ld + nlog;
+        const f32x4 a0 = *(const f32x4*)ad, a1 = *(const f32x4*)(ad + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+      }
+      if (geglu) {
+        float g[8];
+        const f32x4 x0 = *(const f32x4*)(sC + row * BN + lcol + 32);
+        const f32x4 x1 = *(const f32x4*)(sC + row * BN + lcol + 36);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { g[e] = x0[e]; g[4 + e] = x1[e]; }
+        if (p.bias) {
+          const f32x4 b0 = *(const f32x4*)(p.bias + nlog + 32), b1 = *(const f32x4*)(p.bias + nlog + 36);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { g[e] += b0[e]; g[4 + e] += b1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(g[e]);
+      } else if (p.act != LDM_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = apply_act(p.act, v[e]);
+      }
+      const int64_t ooff = (int64_t)bz * p.stride_c + (int64_t)m * p.ldc_m + ncol;
+      const int64_t roff = (int64_t)bz * p.stride_r + (int64_t)m * p.ldr + ncol;
+      if (p.out_dtype == LDM_BF16) {
+        if (p.residual) {
+          float rr[8];
+          chunk_to_f32(*(const u32x4*)((const bf16_t*)p.residual + roff), rr, bf16_t());
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += rr[e];
+        }
+        *(u32x4*)((bf16_t*)p.out + ooff) = f32_to_chunk(v, bf16_t());
+      } else {
+        if (p.residual) {
+          const f32x4 r0 = *(const f32x4*)((const float*)p.residual + roff);
+          const f32x4 r1 = *(const f32x4*)((const float*)p.residual + roff + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        }
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)((float*)p.out + ooff) = o0;
+        *(f32x4*)((float*)p.out + ooff + 4) = o1;
+      }
+    }
+    return;
+  }
+
+  // ---- generic (unaligned / transposed) epilogue straight from the accumulators ----
   if (p.act == LDM_ACT_GEGLU) {
     if constexpr ((TN & 1) == 0) {
 #pragma unroll
@@ -321,6 +477,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         }
       }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // split-K reduce + epilogue: one thread per output element
@@ -348,12 +505,13 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
-constexpr TileCfg kTiles[5] = {{0, 0}, {256, 64}, {128, 128}, {128, 64}, {64, 64}};
+constexpr TileCfg kTiles[5] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}};
+constexpr int kResident[5] = {0, 1, 1, 2, 3};   // workgroups per CU (LDS-limited: 3-stage ring)
 
 template <typename T>
 void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
   switch (cfg) {
-    case 1: hipLaunchKernelGGL((gemm_kernel<T, 256, 64, 4, 1>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2>), grid, dim3(512), 0, s, a); break;
     case 2: hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
@@ -362,47 +520,44 @@ void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Choose tile config + split-K for a problem.  256 CUs, 2 resident blocks per CU.
+// Choose tile config + split-K jointly with a small cost model calibrated on MI355X
+// (tools/gemm_bench.py): a launch runs in rounds of (256 CUs x resident workgroups)
+// tiles; a round costs (K-tiles per split + a fixed prologue/epilogue overhead) x the
+// measured time one CU needs for one K-tile of that configuration with its resident
+// workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
+  static const double kStepUs[5] = {0, 0.99, 0.72, 0.67, 0.565};   // bf16, per round per K-tile
+  static const double kOverheadSteps[5] = {0, 6, 5, 4, 4};          // prologue + epilogue, in K-tiles
+  static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
   const int bke = 128 / esize;
   const int ktiles = cdiv(p->K, bke);
-  int cfg = p->tile;
-  if (cfg <= 0 || cfg > 4) {
-    const bool geglu = p->act == LDM_ACT_GEGLU;
-    double best = -1;
-    cfg = 2;
-    for (int c = 1; c <= 4; ++c) {
-      if (geglu && c > 2) continue;
-      const TileCfg t = kTiles[c];
-      const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
-      const double useful = (double)p->M * p->N * p->batch / (tiles * t.bm * t.bn);
-      // machine fill: tiles are executed in waves of 512 resident blocks
-      const double waves = tiles / 512.0;
-      const double fill = waves >= 1.0 ? waves / (double)((int64_t)(waves + 0.999999)) : 1.0;
-      // arithmetic intensity preference (bigger tiles re-read less through L2/LDS)
-      const double ai = (double)t.bm * t.bn / (t.bm + t.bn) / 64.0;  // 1.0 for 128x128
-      double score = useful * fill * (0.75 + 0.25 * ai);
-      if (tiles < 256.0 && ktiles < 8) score *= tiles / 256.0;  // cannot be rescued by split-K
-      if (score > best) { best = score; cfg = c; }
+  const bool geglu = p->act == LDM_ACT_GEGLU;
+  const double f32x = esize == 4 ? 8.0 : 1.0;   // f32 MFMA: 1/16 the rate at half the K per tile
+  double best = 1e30;
+  int best_cfg = 2, best_split = 1;
+  for (int c = 1; c <= 4; ++c) {
+    if (p->tile > 0 && p->tile <= 4 && c != p->tile) continue;
+    if (geglu && c > 2) continue;
+    const TileCfg t = kTiles[c];
+    const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
+    for (int split : kSplits) {
+      if (p->split_k > 0 && split != p->split_k) continue;
+      // split-K only rescues launches that cannot fill the machine once, and must fit
+      // the caller's workspace
+      if (split > 1 && (p->batch != 1 || ktiles / split < 4 || tiles >= 256.0 * kResident[c] ||
+                        (p->split_k <= 0 && (!p->workspace || (size_t)split * p->M * p->N * 4 > p->workspace_bytes))))
+        continue;
+      const int kps = cdiv(ktiles, split);
+      const double rounds = (double)(int64_t)((tiles * split + 256.0 * kResident[c] - 1) / (256.0 * kResident[c]));
+      double us = rounds * (kps + kOverheadSteps[c]) * kStepUs[c] * f32x;
+      if (split > 1) us += 3.0 + (double)p->M * p->N * 4.0 * (split + 1) / 3.0e6;   // bytes / (3 TB/s) in us
+      if (us < best) { best = us; best_cfg = c; best_split = split; }
     }
   }
-  int split = p->split_k;
-  if (split <= 0) {
-    split = 1;
-    if (p->batch == 1) {
-      const TileCfg t = kTiles[cfg];
-      const int tiles = cdiv(p->M, t.bm) * cdiv(p->N, t.bn);
-      if (tiles < 192 && ktiles >= 8) {
-        split = (384 + tiles - 1) / tiles;
-        if (split > ktiles / 4) split = ktiles / 4;
-        if (split > 32) split = 32;
-        if (split < 1) split = 1;
-      }
-    }
-  }
-  if (p->batch != 1) split = 1;
-  *cfg_out = cfg;
-  *split_out = split;
+  if (p->split_k > 0 && p->batch == 1) best_split = p->split_k;
+  if (p->tile > 0 && p->tile <= 4) best_cfg = p->tile;
+  *cfg_out = best_cfg;
+  *split_out = best_split;
 }
 
 }  // namespace
@@ -420,24 +575,35 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   LDM_CHECK_ARG(p->out_dtype == LDM_F32 || p->out_dtype == LDM_BF16, "ldm_gemm: bad out_dtype");
   LDM_CHECK_ARG(p->M > 0 && p->N > 0 && p->K > 0 && p->batch > 0, "ldm_gemm: bad M/N/K/batch");
   const int esize = p->dtype == LDM_BF16 ? 2 : 4;
+  const int osize = p->out_dtype == LDM_BF16 ? 2 : 4;
   const int epc = 16 / esize, bke = 8 * epc;
   LDM_CHECK_ARG(p->K % epc == 0, "ldm_gemm: K=%d must be a multiple of %d", p->K, epc);
   LDM_CHECK_ARG(((uintptr_t)p->a % 16) == 0 && ((uintptr_t)p->w % 16) == 0,
                 "ldm_gemm: a/w must be 16-byte aligned");
   LDM_CHECK_ARG(p->lda % epc == 0 && p->stride_a % epc == 0 && p->stride_w % epc == 0,
                 "ldm_gemm: lda/stride_a/stride_w must be multiples of %d elements", epc);
+  int64_t a_bytes;
   if (p->conv) {
     LDM_CHECK_ARG(p->Cin > 0 && p->Cin % bke == 0, "ldm_gemm(conv): Cin=%d must be a multiple of %d",
                   p->Cin, bke);
     LDM_CHECK_ARG(p->K == 9 * p->Cin, "ldm_gemm(conv): K must be 9*Cin");
     LDM_CHECK_ARG(p->stride == 1 || p->stride == 2, "ldm_gemm(conv): stride must be 1 or 2");
     LDM_CHECK_ARG(p->B > 0 && p->H > 0 && p->W > 0 && p->OH > 0 && p->OW > 0, "ldm_gemm(conv): dims");
+    LDM_CHECK_ARG(p->H < 32768 && p->W < 32768, "ldm_gemm(conv): H/W too large");
+    LDM_CHECK_ARG(!(p->upsample && p->stride != 1), "ldm_gemm(conv): upsample needs stride 1");
     const int hs = p->upsample ? 2 * p->H : p->H, wsz = p->upsample ? 2 * p->W : p->W;
     LDM_CHECK_ARG(p->OH == (hs + 2 - 3) / p->stride + 1 && p->OW == (wsz + 2 - 3) / p->stride + 1,
                   "ldm_gemm(conv): OH/OW inconsistent with H/W/stride/upsample");
     LDM_CHECK_ARG(p->M == p->B * p->OH * p->OW, "ldm_gemm(conv): M != B*OH*OW");
     LDM_CHECK_ARG(p->batch == 1, "ldm_gemm(conv): batch must be 1");
+    a_bytes = (((int64_t)p->B * p->H * p->W - 1) * p->lda + p->Cin) * esize;
+  } else {
+    a_bytes = (((int64_t)p->M - 1) * p->lda + p->K) * esize;
   }
+  const int64_t w_bytes = (int64_t)p->N * p->K * esize;
+  LDM_CHECK_ARG(a_bytes < (1ll << 31) && w_bytes < (1ll << 31),
+                "ldm_gemm: operand extent must be < 2 GiB (a=%lld w=%lld bytes)", (long long)a_bytes,
+                (long long)w_bytes);
   if (p->addend) LDM_CHECK_ARG(p->add_rows > 0, "ldm_gemm: add_rows must be > 0 with addend");
   if (p->act == LDM_ACT_GEGLU) {
     LDM_CHECK_ARG(p->N % 64 == 0, "ldm_gemm: GEGLU needs N %% 64 == 0");
@@ -455,10 +621,20 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   a.lda = p->lda; a.ldr = p->ldr; a.ldc_m = p->ldc_m; a.ldc_n = p->ldc_n;
   a.stride_a = p->stride_a; a.stride_w = p->stride_w; a.stride_c = p->stride_c; a.stride_r = p->stride_r;
   a.add_ld = p->add_ld; a.M = p->M; a.N = p->N; a.K = p->K; a.batch = p->batch;
+  a.a_bytes = (uint32_t)a_bytes; a.w_bytes = (uint32_t)w_bytes;
   a.add_rows = p->add_rows > 0 ? p->add_rows : 1;
   a.conv = p->conv; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.OH = p->OH; a.OW = p->OW;
   a.stride = p->stride; a.upsample = p->upsample; a.act = p->act; a.out_dtype = p->out_dtype;
   a.alpha = p->alpha;
+  // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
+  const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
+  auto al = [](const void* q, int by) { return ((uintptr_t)q % by) == 0; };
+  { const char* dbg = getenv("LDM_GEMM_DEBUG"); a.debug = dbg ? atoi(dbg) : 0; }
+  a.vec_epilogue =
+      p->ldc_n == 1 && nout % 8 == 0 && p->ldc_m % 8 == 0 && p->stride_c % 8 == 0 && al(p->out, 16) &&
+      (!p->residual || (p->ldr % 8 == 0 && p->stride_r % 8 == 0 && al(p->residual, 16))) &&
+      (!p->bias || al(p->bias, 16)) &&
+      (!p->addend || (al(p->addend, 16) && p->add_ld % 4 == 0));
   a.ktiles = cdiv(p->K, bke);
   a.split_k = split;
   a.ktiles_per_split = cdiv(a.ktiles, split);
@@ -484,7 +660,6 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   int st = ldm_launch_status("ldm_gemm");
   if (st != LDM_OK) return st;
   if (split > 1) {
-    const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
     int64_t total = (int64_t)p->M * nout;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
