@@ -93,12 +93,31 @@ class LatentDiffusionModel(object):
     self._ddim_sqrt_recipm1_alphas_cumprod = self._sqrt_recipm1_alphas_cumprod[self._ddim_steps]
 
     self.device = getattr(unet, "device", torch.device("cuda:0"))
-    # device tables: per index (c1, c2, a_prev, sigma) after the cast of _extract
-    coef = np.stack([self._ddim_sqrt_recip_alphas_cumprod, self._ddim_sqrt_recipm1_alphas_cumprod,
-                     self._ddim_alphas_cumprod_prev, self._ddim_sigmas], axis=1).astype(np.float32)
-    self._coef_dev = torch.from_numpy(coef).to(self.device)
-    self._steps_dev = torch.from_numpy(self._ddim_steps.copy()).to(self.device)
-    self._index_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+    self._tables = None
+
+  def _device_tables(self):
+    """Device copies of the schedule, made on first use: per DDIM index the row
+    (c1, c2, a_prev, sigma) after the float32 cast of `_extract`, the int32 step table
+    and the device-resident loop index."""
+    if self._tables is None:
+      coef = np.stack([self._ddim_sqrt_recip_alphas_cumprod, self._ddim_sqrt_recipm1_alphas_cumprod,
+                       self._ddim_alphas_cumprod_prev, self._ddim_sigmas], axis=1).astype(np.float32)
+      self._tables = (torch.from_numpy(coef).to(self.device),
+                      torch.from_numpy(self._ddim_steps.copy()).to(self.device),
+                      torch.zeros(1, dtype=torch.int32, device=self.device))
+    return self._tables
+
+  @property
+  def _coef_dev(self):
+    return self._device_tables()[0]
+
+  @property
+  def _steps_dev(self):
+    return self._device_tables()[1]
+
+  @property
+  def _index_dev(self):
+    return self._device_tables()[2]
 
   def decode_first_stage(self, latents):
     """model_runners.py:425-434: latents / scale_factor, then the autoencoder's decode
