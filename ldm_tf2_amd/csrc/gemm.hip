@@ -98,7 +98,8 @@ __device__ __forceinline__ float apply_act(int act, float v) {
   return v;
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+// MODE: 0 = plain rows, 1 = 3x3 conv (stride 1/2), 2 = 3x3 conv over the nearest-2x upsampled image
+template <typename T, int BM, int BN, int WM, int WN, int MODE>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // The body uses LDS address-space pointers and gfx950 inline asm, which only the
   // device pass can parse; the host pass just needs the launch stub.
@@ -112,11 +113,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
   constexpr int BKE = 8 * EPC;
-  constexpr int NSTAGE = 3;
+  constexpr int NSTAGE = 2;
   constexpr int STAGE = (BM + BN) * 128;
-  constexpr int SMEM = NSTAGE * STAGE;
+  constexpr int SMEM = NSTAGE * STAGE > BM * BN * 4 ? NSTAGE * STAGE : BM * BN * 4;
   static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile");
-  static_assert(BM * BN * 4 <= SMEM, "epilogue tile must fit the staging LDS");
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -156,21 +156,21 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // (l&7) ^ ((row>>1)&7) of that row (the read side applies the same XOR).
   // conv: a_base = byte offset of pixel (b, oy*s-1, ox*s-1) (+ chunk), a_mask = 9 tap-valid bits
   //       upsample: a_base = byte offset of image b, a_aux = ((oy-1) << 16) | ((ox-1) & 0xffff)
-  // gemm: a_base = byte offset of row m (+ chunk), a_mask = row valid
-  int a_base[LA], a_mask[LA], a_aux[LA], a_kc[LA];
+  // gemm: a_base = byte offset of row m (+ chunk), or kOOB for rows >= M
+  int a_base[LA], a_mask[LA], a_aux[LA];
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
     const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int ck = (lane & 7) ^ ((row >> 1) & 7);
     const int m = m0 + row;
-    a_base[i] = 0; a_mask[i] = 0; a_aux[i] = 0; a_kc[i] = ck * EPC;
+    a_base[i] = MODE == 0 ? (int)kOOB : 0; a_mask[i] = 0; a_aux[i] = 0;
     if (m < p.M) {
-      if (p.conv) {
+      if constexpr (MODE != 0) {
         const int ohw = p.OH * p.OW;
         const int b = m / ohw, rem = m - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
         const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
-        const int Hs = p.upsample ? p.H * 2 : p.H, Ws = p.upsample ? p.W * 2 : p.W;
+        const int Hs = MODE == 2 ? p.H * 2 : p.H, Ws = MODE == 2 ? p.W * 2 : p.W;
         int mask = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
           if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) mask |= 1 << t;
         }
         a_mask[i] = mask;
-        if (p.upsample) {
+        if constexpr (MODE == 2) {
           a_base[i] = (int)((int64_t)b * p.H * p.W * p.lda * ES) + ck * 16;
           a_aux[i] = (iy0 << 16) | (ix0 & 0xffff);
         } else {
@@ -186,31 +186,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         }
       } else {
         a_base[i] = (int)((int64_t)m * p.lda * ES) + ck * 16;
-        a_mask[i] = 1;
       }
     }
   }
-  int b_base[LB], b_kc[LB];
+  // weights: byte offset of row n (+ chunk), or kOOB for rows >= N (stays out of range for
+  // every K offset we add: num_records < 2^31 and offsets are compared unsigned)
+  int b_base[LB];
 #pragma unroll
   for (int i = 0; i < LB; ++i) {
     const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int ck = (lane & 7) ^ ((row >> 1) & 7);
     const int n = n0 + row;
-    b_kc[i] = ck * EPC;
-    b_base[i] = n < p.N ? (int)((int64_t)n * p.K * ES) + ck * 16 : -1;
+    b_base[i] = n < p.N ? (int)((int64_t)n * p.K * ES) + ck * 16 : (int)kOOB;
   }
   const int row_pitch = (int)(p.lda * ES);          // bytes per pixel
   const int line_pitch = p.W * row_pitch;           // bytes per image line
 
+  // K-tile kt -> loads into `stage`.  K is a multiple of the K-tile (checked on the host),
+  // so only rows (M/N tails, conv padding) are ever masked, never K.
   auto issue_tile = [&](int kt, int stage) {
     char* dA = smem + stage * STAGE + wave * 1024;
-    char* dB = smem + stage * STAGE + BM * 128 + wave * 1024;
-    const int k0 = kt * BKE;
-    if (p.conv) {
-      const int tap = k0 / p.Cin;                    // scalar
-      const int cib = (k0 - tap * p.Cin) * ES;       // channel byte offset
+    char* dB = dA + BM * 128;
+    int kb;                                          // byte column of the weight matrix
+    if constexpr (MODE != 0) {
+      // conv K order: channel chunk OUTER, tap INNER (kt = chunk*9 + tap).  The nine taps
+      // of one 128-byte channel slice re-read the same pixels on consecutive K-tiles
+      // (L1/L2 hits).  Only the summation order changes; the weight matrix keeps its
+      // (tap, ci) layout.
+      const int cc = kt / 9;
+      const int tap = kt - cc * 9;
+      const int cib = cc * 128;                      // channel byte offset
+      kb = tap * p.Cin * ES + cib;
       const int kh = tap / 3, kw = tap - kh * 3;
-      if (p.upsample) {
+      if constexpr (MODE == 2) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) {
           const int iy = ((a_aux[i] >> 16) + kh) >> 1;
@@ -229,21 +237,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         }
       }
     } else {
-      const int kb = k0 * ES;
+      kb = kt * 128;
 #pragma unroll
-      for (int i = 0; i < LA; ++i) {
-        const uint32_t off = (uint32_t)(a_base[i] + kb);
+      for (int i = 0; i < LA; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dA + i * NW * 1024), 16,
-                                                 (a_mask[i] && (k0 + a_kc[i]) < p.K) ? off : kOOB, 0, 0, 0);
-      }
+                                                 (uint32_t)a_base[i] + (uint32_t)kb, 0, 0, 0);
     }
-    const int kb = k0 * ES;
 #pragma unroll
-    for (int i = 0; i < LB; ++i) {
-      const uint32_t off = (uint32_t)(b_base[i] + kb);
+    for (int i = 0; i < LB; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dB + i * NW * 1024), 16,
-                                               (b_base[i] >= 0 && (k0 + b_kc[i]) < p.K) ? off : kOOB, 0, 0, 0);
-    }
+                                               (uint32_t)b_base[i] + (uint32_t)kb, 0, 0, 0);
   };
 
   f32x16 acc[TM][TN];
@@ -256,32 +259,33 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
 
   const int lr = lane & 31, lh = lane >> 5;
   const int sw = (lr >> 1) & 7;
-  const int offA = (wm * WTM + lr) * 128;
-  const int offB = BM * 128 + (wn * WTN + lr) * 128;
+  // fragment byte offsets inside a stage: 4 swizzled k-group columns, hoisted out of the loop
+  int offA[4], offB[4];
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) {
+    const int coff = ((kg * 2 + lh) ^ sw) << 4;
+    offA[kg] = (wm * WTM + lr) * 128 + coff;
+    offB[kg] = BM * 128 + (wn * WTN + lr) * 128 + coff;
+  }
 
+  // 2-stage ring, prefetch distance 1: at the top of K-tile t every outstanding LDS-DMA
+  // belongs to tile t; after the wait + ONE barrier, tile t is visible to all waves and all
+  // waves have finished reading the other stage (tile t-1), which tile t+1 may now overwrite.
   if (nk > 0) issue_tile(kt_begin, 0);
-  if (nk > 1) issue_tile(kt_begin + 1, 1);
-  int st_cur = 0, st_nxt = 2;     // stage of tile t / stage tile t+2 goes to
   for (int t = 0; t < nk; ++t) {
-    // tile t has landed once at most the NL loads of tile t+1 are still outstanding
-    if (t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // everyone's pieces of tile t landed; everyone left tile t-1
-    if (t + 2 < nk) issue_tile(kt_begin + t + 2, st_nxt);
-    const char* cA = smem + st_cur * STAGE + offA;
-    const char* cB = smem + st_cur * STAGE + offB;
-    // all fragment reads of the K-tile are issued up front (the LDS pipe stays full and
-    // only the first MFMA waits a full LDS latency); the MFMAs then drain them in order
+    const int st = t & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t + 1 < nk) issue_tile(kt_begin + t + 1, st ^ 1);
+    const char* cS = smem + st * STAGE;
     u32x4 fa[4][TM], fb[4][TN];
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
-      const int coff = ((kg * 2 + lh) ^ sw) << 4;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[kg][i] = *(const u32x4*)(cA + i * 32 * 128 + coff);
+      for (int i = 0; i < TM; ++i) fa[kg][i] = *(const u32x4*)(cS + offA[kg] + i * 32 * 128);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[kg][j] = *(const u32x4*)(cB + j * 32 * 128 + coff);
+      for (int j = 0; j < TN; ++j) fb[kg][j] = *(const u32x4*)(cS + offB[kg] + j * 32 * 128);
     }
-    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg)
@@ -290,8 +294,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) mma32(acc[i][j], fa[kg][i], fb[kg][j], T());
     __builtin_amdgcn_s_setprio(0);
-    st_cur = st_cur == NSTAGE - 1 ? 0 : st_cur + 1;
-    st_nxt = st_nxt == NSTAGE - 1 ? 0 : st_nxt + 1;
   }
   __syncthreads();   // all waves done with the staging LDS before the epilogue reuses it
 
@@ -506,16 +508,22 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
 constexpr TileCfg kTiles[5] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}};
-constexpr int kResident[5] = {0, 1, 1, 2, 3};   // workgroups per CU (LDS-limited: 3-stage ring)
+constexpr int kResident[5] = {0, 1, 2, 3, 5};   // workgroups per CU (LDS-limited: 2-stage ring)
 
-template <typename T>
+template <typename T, int MODE>
 void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
   switch (cfg) {
-    case 1: hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2>), grid, dim3(512), 0, s, a); break;
-    case 2: hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2>), grid, dim3(256), 0, s, a); break;
-    case 3: hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
-    default: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2>), grid, dim3(256), 0, s, a); break;
+    case 1: hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2, MODE>), grid, dim3(512), 0, s, a); break;
+    case 2: hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
+    case 3: hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
+    default: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
   }
+}
+template <typename T>
+void launch_mode(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  if (!a.conv) launch_cfg<T, 0>(cfg, a, grid, s);
+  else if (!a.upsample) launch_cfg<T, 1>(cfg, a, grid, s);
+  else launch_cfg<T, 2>(cfg, a, grid, s);
 }
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -526,8 +534,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // measured time one CU needs for one K-tile of that configuration with its resident
 // workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
-  static const double kStepUs[5] = {0, 0.99, 0.72, 0.67, 0.565};   // bf16, per round per K-tile
-  static const double kOverheadSteps[5] = {0, 6, 5, 4, 4};          // prologue + epilogue, in K-tiles
+  static const double kStepUs[5] = {0, 0.82, 0.82, 0.75, 0.87};     // bf16, per round per K-tile (resident WGs co-running)
+  static const double kOverheadSteps[5] = {0, 8, 8, 7, 6};          // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
   const int bke = 128 / esize;
   const int ktiles = cdiv(p->K, bke);
@@ -577,7 +585,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   const int esize = p->dtype == LDM_BF16 ? 2 : 4;
   const int osize = p->out_dtype == LDM_BF16 ? 2 : 4;
   const int epc = 16 / esize, bke = 8 * epc;
-  LDM_CHECK_ARG(p->K % epc == 0, "ldm_gemm: K=%d must be a multiple of %d", p->K, epc);
+  LDM_CHECK_ARG(p->K % bke == 0, "ldm_gemm: K=%d must be a multiple of the K-tile (%d elements)", p->K, bke);
   LDM_CHECK_ARG(((uintptr_t)p->a % 16) == 0 && ((uintptr_t)p->w % 16) == 0,
                 "ldm_gemm: a/w must be 16-byte aligned");
   LDM_CHECK_ARG(p->lda % epc == 0 && p->stride_a % epc == 0 && p->stride_w % epc == 0,
@@ -655,8 +663,8 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   LDM_CHECK_ARG(nblk < (1ll << 31), "ldm_gemm: grid too large");
   dim3 grid((unsigned)nblk);
   hipStream_t s = (hipStream_t)stream;
-  if (p->dtype == LDM_BF16) launch_cfg<bf16_t>(cfg, a, grid, s);
-  else launch_cfg<float>(cfg, a, grid, s);
+  if (p->dtype == LDM_BF16) launch_mode<bf16_t>(cfg, a, grid, s);
+  else launch_mode<float>(cfg, a, grid, s);
   int st = ldm_launch_status("ldm_gemm");
   if (st != LDM_OK) return st;
   if (split > 1) {

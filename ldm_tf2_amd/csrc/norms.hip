@@ -39,12 +39,22 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
 #pragma unroll
     for (int e = 0; e < EPC; ++e) { a1[e] = 0.f; a2[e] = 0.f; }
     if (pl < gg.P && v < gg.nvec) {
-      for (int p = p_begin + pl; p < p_end; p += gg.P) {
-        const u32x4 c = *(const u32x4*)(xb + (int64_t)p * ldx + v * EPC);
-        float f[EPC];
-        chunk_to_f32(c, f, T());
+      // 4 independent 16-byte loads in flight per lane (the kernel is latency-bound otherwise)
+      for (int p = p_begin + pl; p < p_end; p += 4 * gg.P) {
+        u32x4 c[4];
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) { a1[e] += f[e]; a2[e] += f[e] * f[e]; }
+        for (int u = 0; u < 4; ++u) {
+          const int pp = p + u * gg.P;
+          c[u] = u32x4{0u, 0u, 0u, 0u};
+          if (pp < p_end) c[u] = *(const u32x4*)(xb + (int64_t)pp * ldx + v * EPC);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float f[EPC];
+          chunk_to_f32(c[u], f, T());
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) { a1[e] += f[e]; a2[e] += f[e] * f[e]; }
+        }
       }
 #pragma unroll
       for (int e = 0; e < EPC; ++e) {
@@ -109,22 +119,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
       sc[e] = s_rstd[g] * gamma[c];
       sh[e] = beta[c];
     }
-    for (int p = p_begin + pl; p < p_end; p += gg.P) {
-      const u32x4 cin = *(const u32x4*)(xb + (int64_t)p * ldx + v * EPC);
-      float f[EPC];
-      chunk_to_f32(cin, f, T());
+    for (int p = p_begin + pl; p < p_end; p += 4 * gg.P) {
+      u32x4 cin[4];
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        float y = (f[e] - mu[e]) * sc[e] + sh[e];
-        f[e] = do_silu ? silu_f(y) : y;
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * gg.P;
+        if (pp < p_end) cin[u] = *(const u32x4*)(xb + (int64_t)pp * ldx + v * EPC);
       }
-      *(u32x4*)(ob + (int64_t)p * ldo + v * EPC) = f32_to_chunk(f, T());
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pp = p + u * gg.P;
+        if (pp < p_end) {
+          float f[EPC];
+          chunk_to_f32(cin[u], f, T());
+#pragma unroll
+          for (int e = 0; e < EPC; ++e) {
+            float y = (f[e] - mu[e]) * sc[e] + sh[e];
+            f[e] = do_silu ? silu_f(y) : y;
+          }
+          *(u32x4*)(ob + (int64_t)pp * ldo + v * EPC) = f32_to_chunk(f, T());
+        }
+      }
     }
   }
 }
 
-// one wave per row; the row lives in registers between the two passes
-template <typename T>
+// LPR lanes share a row (64/LPR rows per wave), each lane keeps <= 8 16-byte pieces of
+// its row in registers between the passes; reductions are LPR-wide butterflies.  Small
+// C therefore packs several rows into a wave instead of idling most of its lanes, and
+// every lane has all its loads in flight at once.
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
@@ -132,29 +156,37 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
                                                         int C, float eps) {
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int MAXV = 8;
+  constexpr int RPW = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+  const int sub = lane % LPR;
+  const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool rok = row < rows;
   const int nvec = C / EPC;
-  const T* xr = x + (int64_t)row * ldx;
+  const T* xr = x + (int64_t)(rok ? row : 0) * ldx;
   u32x4 buf[MAXV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + i * 64;
+    const int v = sub + i * LPR;
+    if (v < nvec) buf[i] = *(const u32x4*)(xr + v * EPC);
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = sub + i * LPR;
     if (v < nvec) {
-      buf[i] = *(const u32x4*)(xr + v * EPC);
       float f[EPC];
       chunk_to_f32(buf[i], f, T());
 #pragma unroll
       for (int e = 0; e < EPC; ++e) s += f[e];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + i * 64;
+    const int v = sub + i * LPR;
     if (v < nvec) {
       float f[EPC];
       chunk_to_f32(buf[i], f, T());
@@ -162,18 +194,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
       for (int e = 0; e < EPC; ++e) { const float d = f[e] - mean; q += d * d; }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  if (!rok) return;
   T* orow = out + (int64_t)row * ldo;
 #pragma unroll
   for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + i * 64;
+    const int v = sub + i * LPR;
     if (v < nvec) {
       float f[EPC];
       chunk_to_f32(buf[i], f, T());
+      const f32x4* gp = (const f32x4*)(gamma + v * EPC);
+      const f32x4* bp = (const f32x4*)(beta + v * EPC);
 #pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const int c = v * EPC + e;
-        f[e] = (f[e] - mean) * rstd * gamma[c] + beta[c];
+      for (int h = 0; h < EPC / 4; ++h) {
+        const f32x4 g4 = gp[h], b4 = bp[h];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) f[h * 4 + e] = (f[h * 4 + e] - mean) * rstd * g4[e] + b4[e];
       }
       *(u32x4*)(orow + v * EPC) = f32_to_chunk(f, T());
     }
@@ -284,14 +322,27 @@ extern "C" int ldm_layernorm(const void* x, int64_t ldx, const float* gamma, con
                 "ldm_layernorm: C=%d must be a multiple of %d and <= %d", C, epc, 512 * epc);
   LDM_CHECK_ARG(ldx % epc == 0 && ldo % epc == 0 && ((uintptr_t)x % 16) == 0 &&
                     ((uintptr_t)out % 16) == 0, "ldm_layernorm: alignment");
-  dim3 grid((rows + 3) / 4);
+  LDM_CHECK_ARG(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0, "ldm_layernorm: gamma/beta alignment");
+  const int nvec = C / epc;
+  int lpr = 4;
+  while (lpr < 64 && lpr * 8 < nvec) lpr *= 2;
+  const int rows_per_block = 4 * (64 / lpr);
+  dim3 grid((rows + rows_per_block - 1) / rows_per_block);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == LDM_BF16)
-    hipLaunchKernelGGL(layernorm_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ldx, gamma,
-                       beta, (bf16_t*)out, ldo, rows, C, eps);
-  else
-    hipLaunchKernelGGL(layernorm_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ldx, gamma,
-                       beta, (float*)out, ldo, rows, C, eps);
+#define LN_LAUNCH(TT, L)                                                                         \
+  hipLaunchKernelGGL((layernorm_kernel<TT, L>), grid, dim3(256), 0, s, (const TT*)x, ldx, gamma, \
+                     beta, (TT*)out, ldo, rows, C, eps)
+#define LN_SWITCH(TT)                     \
+  switch (lpr) {                          \
+    case 4: LN_LAUNCH(TT, 4); break;      \
+    case 8: LN_LAUNCH(TT, 8); break;      \
+    case 16: LN_LAUNCH(TT, 16); break;    \
+    case 32: LN_LAUNCH(TT, 32); break;    \
+    default: LN_LAUNCH(TT, 64); break;    \
+  }
+  if (dtype == LDM_BF16) { LN_SWITCH(bf16_t) } else { LN_SWITCH(float) }
+#undef LN_SWITCH
+#undef LN_LAUNCH
   return ldm_launch_status("ldm_layernorm");
 }
 

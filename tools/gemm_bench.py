@@ -31,18 +31,25 @@ GEMMS = [  # (T per row, K, N, count)
 ]
 
 
-def time_fn(fn, rounds):
+def time_fn(fn, rounds=5, inner=10):
+  """GPU time per call: `inner` calls captured in a HIP graph and replayed (no host
+  launch latency in the measurement); best of `rounds`."""
   fn()
+  torch.cuda.synchronize()
+  g = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(g):
+    for _ in range(inner):
+      fn()
+  g.replay()
   torch.cuda.synchronize()
   best = 1e9
   for _ in range(rounds):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(3):
-      fn()
+    g.replay()
     e1.record()
     e1.synchronize()
-    best = min(best, e0.elapsed_time(e1) / 3)
+    best = min(best, e0.elapsed_time(e1) / inner)
   return best
 
 
