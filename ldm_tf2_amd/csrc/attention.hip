@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;          // running max (log2 domain) and sum
+  const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
 
   u32x4 rk[CK], rv[CV];
   auto load_tile = [&](int kt0) {
@@ -166,34 +167,47 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
       }
     }
     // ---- online softmax (per lane = per query) ------------------------------------
+    // The softmax VALU work outweighs the MFMAs at these head sizes, so it is kept to
+    // max + fma + exp2 + add per logit: the scale (applied after q.k^T, unet.py:281) is
+    // folded with log2(e) into the exp2 argument (scale > 0 commutes with max); keys are
+    // masked only in the tile that crosses Tk; the running max is only advanced -- and O,
+    // l rescaled -- when some query's max grew by more than 2^8 (softmax is invariant to
+    // the reference point; P then stays <= 256, harmless in bf16/f32).
+    if (kt0 + KT > p.Tk) {   // wave-uniform
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt0 + j * 32 + TR::kappa((r & 3) + 8 * (r >> 2) + 4 * lh);
+          if (key >= p.Tk) s[j][r] = -INFINITY;
+        }
+    }
     float mt = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt0 + j * 32 + TR::kappa((r & 3) + 8 * (r >> 2) + 4 * lh);
-        const float v = key < p.Tk ? s[j][r] * p.scale : -INFINITY;
-        s[j][r] = v;
-        mt = fmaxf(mt, v);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float m_new = fmaxf(m_run, mt);
-    const float alpha = __expf(m_run - m_new);
-    m_run = m_new;
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[j][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c2;
+    if (!__all(mt <= m_run + 8.0f)) {   // wave-uniform; always taken for the first tile
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < ND; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
     float ls = 0.f;
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float e = __expf(s[j][r] - m_new);
+        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][r], c2, -m_run));
         s[j][r] = e;
         ls += e;
       }
-    l_run = l_run * alpha + ls;
-#pragma unroll
-    for (int d = 0; d < ND; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    l_run += ls;
     // ---- O^T += V^T . P^T -------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)

@@ -36,15 +36,18 @@ static inline int ldm_launch_status(const char* what) {
 
 // ---- scalar conversions ----------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
+// f32 -> bf16, round-to-nearest-even, NaN stays NaN: gfx950's v_cvt_pk_bf16_f32 converts
+// two values in ONE instruction (a bit-twiddled software rounding costs ~6 VALU ops per
+// value and was the hottest part of the attention softmax and of every bf16 epilogue).
+// Written as a vector convert (not inline asm) so that hipcc emits the instruction itself
+// and pads the VALU-write -> MFMA-read hazard when the result feeds an MFMA operand.
+typedef __attribute__((ext_vector_type(2))) __bf16 ldm_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float ldm_f32x2;
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const ldm_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, ldm_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.0f) & 0xffffu); }
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {

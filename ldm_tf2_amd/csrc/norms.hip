@@ -64,13 +64,25 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     }
   }
   __syncthreads();
+  // 8 lanes per group split its (pixel-lane, channel) cells, then a 3-step butterfly
+  // (fixed order: deterministic).  G <= 32 groups -> one pass of the 256 threads.
   const int cpg = C / G;
-  for (int g = tid; g < G; g += 256) {
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    const int g = g0 + (tid >> 3), sub = tid & 7;
     float t1 = 0.f, t2 = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c)
-      for (int q = 0; q < gg.P; ++q) { t1 += s1[q * C + c]; t2 += s2[q * C + c]; }
-    float* o = partial + (((int64_t)b * nchunks + chunk) * G + g) * 2;
-    o[0] = t1; o[1] = t2;
+    if (g < G) {
+      const int cells = cpg * gg.P;
+      for (int i = sub; i < cells; i += 8) {
+        const int q = i / cpg, c = g * cpg + (i - q * cpg);
+        t1 += s1[q * C + c]; t2 += s2[q * C + c];
+      }
+    }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+    if (g < G && sub == 0) {
+      float* o = partial + (((int64_t)b * nchunks + chunk) * G + g) * 2;
+      o[0] = t1; o[1] = t2;
+    }
   }
 }
 
@@ -88,18 +100,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int cpg = C / G;
-  for (int g = tid; g < G; g += 256) {
+  for (int g0 = 0; g0 < G; g0 += 32) {
+    const int g = g0 + (tid >> 3), sub = tid & 7;   // 8 lanes per group over the chunks
     float t1 = 0.f, t2 = 0.f;
-    for (int c = 0; c < nchunks; ++c) {
-      const float* o = partial + (((int64_t)b * nchunks + c) * G + g) * 2;
-      t1 += o[0]; t2 += o[1];
+    if (g < G)
+      for (int c = sub; c < nchunks; c += 8) {
+        const float* o = partial + (((int64_t)b * nchunks + c) * G + g) * 2;
+        t1 += o[0]; t2 += o[1];
+      }
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
+    if (g < G && sub == 0) {
+      const float n = (float)HW * (float)cpg;
+      const float mean = t1 / n;
+      float var = t2 / n - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      s_mean[g] = mean;
+      s_rstd[g] = rsqrtf(var + eps);
     }
-    const float n = (float)HW * (float)cpg;
-    const float mean = t1 / n;
-    float var = t2 / n - mean * mean;
-    var = var < 0.f ? 0.f : var;
-    s_mean[g] = mean;
-    s_rstd[g] = rsqrtf(var + eps);
   }
   __syncthreads();
   const int ppc = (HW + achunks - 1) / achunks;
@@ -300,7 +318,10 @@ extern "C" int ldm_groupnorm_apply(const void* x, int64_t ldx, const float* part
   const int epc = dtype == LDM_BF16 ? 8 : 4;
   LDM_CHECK_ARG(partial && gamma && beta && out, "ldm_groupnorm_apply: null pointer");
   LDM_CHECK_ARG(ldo % epc == 0 && ((uintptr_t)out % 16) == 0, "ldm_groupnorm_apply: out alignment");
-  const int achunks = ldm_groupnorm_nchunks(B, HW, C);
+  // fatter blocks than the statistics pass: ~512 workgroups, >= 32 pixels each
+  int achunks = (512 + B - 1) / B;
+  if (achunks > HW / 32) achunks = HW / 32;
+  if (achunks < 1) achunks = 1;
   dim3 grid(achunks, B);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == LDM_BF16)
