@@ -131,6 +131,8 @@ def main():
   ap.add_argument("--guidance", type=float, default=5.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--fuse-gn", action="store_true",
+                  help="A/B: GroupNorm+SiLU as the halo conv's prologue instead of a separate pass")
   args = ap.parse_args()
 
   from ldm_tf2_amd import distributed as D
@@ -159,7 +161,7 @@ def main():
                                      scope="autoencoder"),
   }
   log(rank, f"weights generated in {time.perf_counter() - t_build:.1f}s")
-  unet = UNet(**cfg["unet"], weights=w["unet"], dtype=dtype, device=dev)
+  unet = UNet(**cfg["unet"], weights=w["unet"], dtype=dtype, device=dev, fuse_groupnorm=args.fuse_gn)
   txt = TransformerModel(**cfg["cond_stage_model"], weights=w["cond_stage_model"], dtype=dtype, device=dev)
   ae = AutoencoderKL(**cfg["autoencoder_kl"], weights=w["autoencoder"], dtype=dtype, device=dev)
   ldm = dict(cfg["ldm"], num_ddim_steps=args.ddim_steps)

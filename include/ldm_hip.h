@@ -94,8 +94,16 @@ typedef struct {
   int32_t dtype;         /* of a, w */
   int32_t out_dtype;     /* of out, residual */
   int32_t split_k;       /* 0 = let the library choose */
-  int32_t tile;          /* 0 = auto; else force a tile config (tuning / tests) */
+  int32_t tile;          /* 0 = auto; 1-4 force an implicit-GEMM tile, 11-13 a halo-conv tile */
   float alpha;
+  /* conv prologue (stride-1 halo path only): A := [silu](A*a_scale[b][ci] + a_shift[b][ci]) on
+   * in-image pixels, applied ONCE per element in LDS before the zero padding -- the
+   * GroupNormalization affine (+ tf.nn.silu) that precedes every ResBlock conv
+   * (unet.py:383,390; autoencoder.py:43-51) with scale = rstd*gamma, shift = beta - mean*scale
+   * from ldm_groupnorm_finalize.  float32 [B][Cin]; NULL = no prologue. */
+  const float* a_scale;
+  const float* a_shift;
+  int32_t a_silu;
 } ldm_gemm_params;
 
 int ldm_gemm(const ldm_gemm_params* p, void* stream);
@@ -127,6 +135,15 @@ int ldm_groupnorm_partial(const void* x, int64_t ldx, float* partial, int B, int
 int ldm_groupnorm_apply(const void* x, int64_t ldx, const float* partial, const float* gamma,
                         const float* beta, void* out, int64_t ldo, int B, int HW, int C,
                         int groups, int nchunks, float eps, int silu, int dtype, void* stream);
+/* Instead of ldm_groupnorm_apply: fold the statistics into per-(sample, channel)
+ * scale = rstd*gamma and shift = beta - mean*scale (float32 [B][C]) for a consumer that
+ * normalises on the fly (ldm_gemm's a_scale / a_shift conv prologue). */
+int ldm_groupnorm_finalize(const float* partial, const float* gamma, const float* beta, float* scale,
+                           float* shift, int B, int HW, int C, int groups, int nchunks, float eps,
+                           void* stream);
+/* 1 if ldm_gemm would run these conv params on the halo path (and so accepts a_scale/a_shift),
+ * else 0.  Pure host-side query: no launch. */
+int ldm_conv_prologue_supported(const ldm_gemm_params* p);
 
 /* LayerNormalization over the last axis (unet.py:304-306; transformer.py:165,170,209). */
 int ldm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out,

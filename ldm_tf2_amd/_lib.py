@@ -31,6 +31,7 @@ class GemmParams(C.Structure):
       ("OH", c_i32), ("OW", c_i32), ("stride", c_i32), ("upsample", c_i32),
       ("act", c_i32), ("dtype", c_i32), ("out_dtype", c_i32), ("split_k", c_i32),
       ("tile", c_i32), ("alpha", c_f32),
+      ("a_scale", c_vp), ("a_shift", c_vp), ("a_silu", c_i32),
   ]
 
 
@@ -47,6 +48,9 @@ SIGNATURES = {
                                       c_i32, c_vp]),
     "ldm_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
                                     c_i32, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
+    "ldm_groupnorm_finalize": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                       c_f32, c_vp]),
+    "ldm_conv_prologue_supported": (c_i32, [C.POINTER(GemmParams)]),
     "ldm_layernorm": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32,
                               c_i32, c_vp]),
     "ldm_softmax_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32,

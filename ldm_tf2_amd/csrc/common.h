@@ -17,6 +17,8 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 // ---- error plumbing --------------------------------------------------------
 void ldm_set_error(const char* fmt, ...);
+// conv_halo.hip: 1 = launched by a halo kernel, 0 = not eligible (use implicit GEMM), < 0 error
+int ldm_conv_halo_try(const ldm_gemm_params* p, int cfg, void* stream);
 #define LDM_CHECK_ARG(cond, ...)     \
   do {                               \
     if (!(cond)) {                   \
@@ -87,7 +89,11 @@ __device__ __forceinline__ u32x4 f32_to_chunk(const float (&f)[8], bf16_t) {
 }
 
 // ---- math ------------------------------------------------------------------
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with the hardware exp2 / reciprocal (1 ulp each): 4 instructions instead
+// of the ~15 of an IEEE division -- SiLU runs on every GroupNorm output element.
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }

@@ -1,0 +1,496 @@
+// 3x3 stride-1 convolution with an LDS-staged HALO tile of the input (gfx950 / MI355X).
+//
+// The implicit-GEMM kernel of gemm.hip re-fetches every input pixel once per filter tap
+// (9x) into its LDS A tile.  Here a workgroup owns a TH x TW patch of output pixels (of
+// NI images when the feature map is smaller than the tile) and stages, per 128-byte
+// channel slice, the (TH+2) x (TW+2) input patch ONCE; the nine taps then read their A
+// fragments from that one LDS image at shifted rows.  A-side staging traffic drops ~5x and
+// -- because the slice sits in LDS before any tap uses it -- the producer's GroupNorm
+// affine + SiLU (unet.py:383,390; autoencoder.py:43-51) can be applied to it in place,
+// ONCE per element instead of once per tap, which removes the separate normalise pass.
+//
+//   K loop: channel slice c (outer) x tap (inner); weights stream through a 2-stage LDS
+//   ring (one [BN][64] tile per (c, tap)); the halo image is double-buffered across slices:
+//   slice c+1 arrives in eight pieces, one per tap step, behind the weight tile of the next
+//   step.  Every step: s_waitcnt vmcnt(0) + ONE s_barrier (both loads issued in step t had
+//   a whole step to land).  Zero padding = buffer range check (out-of-range offset -> 0).
+//   nearest-2x upsample (unet.py:44): the halo holds SOURCE pixels; tap rows are
+//   ((ty+kh-1)>>1, (tx+kw-1)>>1) -- no upsampled tensor ever exists.
+//   Same LDS row format as gemm.hip: rows of 8 x 16 B, chunk' = chunk ^ ((row>>1)&7).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+struct HaloArgs {
+  const char* a; const char* w; const float* bias; const float* addend; const char* residual;
+  char* out;
+  const float* a_scale; const float* a_shift;     // [B][Cin] GroupNorm scale/shift or NULL
+  int64_t lda, ldr, ldc, add_ld;
+  uint32_t a_bytes, w_bytes;
+  int B, H, W, Cin, OH, OW, N, M;
+  int add_rows;
+  int th, tw, ni, log_tw, log_thw;                // output-pixel tile geometry
+  int tiles_x, tiles_per_group, tiles_m, tiles_n;
+  int hs_w, hs, hr, hr_pad;                       // halo: row pitch, rows/image, rows, rows padded to 8
+  int nchunks, a_silu, out_dtype;
+};
+
+constexpr uint32_t kOOB = 0x80000000u;
+
+__device__ __forceinline__ void mma32h(f32x16& acc, const u32x4& a, const u32x4& b, bf16_t) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                __builtin_bit_cast(bf16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma32h(f32x16& acc, const u32x4& a, const u32x4& b, float) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc,
+                                               0, 0, 0);
+}
+
+template <typename T, int BM, int BN, int WM, int WN, bool UPS>
+__global__ __launch_bounds__(WM* WN * 64) void conv_halo_kernel(HaloArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = WM * WN;
+  constexpr int NT = NW * 64;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LB = BN / (8 * NW);
+  constexpr int ES = (int)sizeof(T);
+  constexpr int EPC = 16 / ES;
+  constexpr int MAXP = 8;   // halo pieces a thread may own in the GroupNorm pass
+  static_assert(LB >= 1 && TM >= 1 && TN >= 1, "tile");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int HB = p.hr_pad * 128;                  // bytes of one halo image
+  char* sA = smem;                                // [2][HB]
+  char* sB = smem + 2 * HB;                       // [2][BN*128]
+
+  // ---- block -> (spatial tile, n tile), XCD-aware, n fastest -------------------------
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+  const int n0 = tile_n * BN;
+  const int bg = tile_m / p.tiles_per_group, tr = tile_m - bg * p.tiles_per_group;
+  const int tyi = tr / p.tiles_x, txi = tr - tyi * p.tiles_x;
+  const int b0 = bg * p.ni, y0 = tyi * p.th, x0 = txi * p.tw;       // output coords of the tile
+  // source origin of the halo (row -1 / col -1 of the tile, in SOURCE pixel coords)
+  const int sy0 = (UPS ? (y0 >> 1) : y0) - 1, sx0 = (UPS ? (x0 >> 1) : x0) - 1;
+
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w), 0, p.w_bytes, 0x00020000);
+  const int row_pitch = (int)(p.lda * ES);
+
+  // ---- halo staging slots: slot s (one per tap step 0..7) = LDS-DMA instruction
+  // j = s*NW + wave, halo rows 8j..8j+7; lane -> row 8j + (lane>>3), source chunk
+  // (lane&7) ^ ((row>>1)&7).  h_off = byte offset of that pixel's chunk, kOOB if padding.
+  uint32_t h_off[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int h = (s * NW + wave) * 8 + (lane >> 3);
+    const int ck = (lane & 7) ^ ((h >> 1) & 7);
+    uint32_t off = kOOB;
+    if (h < p.hr) {
+      const int img = h / p.hs, rem = h - img * p.hs;
+      const int hy = rem / p.hs_w, hx = rem - hy * p.hs_w;
+      const int sy = sy0 + hy, sx = sx0 + hx, b = b0 + img;
+      if (b < p.B && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W)
+        off = (uint32_t)(((int64_t)(b * p.H + sy) * p.W + sx) * row_pitch) + ck * 16;
+    }
+    h_off[s] = off;
+  }
+  auto issue_halo = [&](int chunk, int s, int buf) {
+    if ((s * NW + wave) * 8 < p.hr_pad)           // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(sA + buf * HB + (s * NW + wave) * 1024), 16,
+                                               h_off[s] + (uint32_t)(chunk * 128), 0, 0, 0);
+  };
+  int b_base[LB];
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int ck = (lane & 7) ^ ((row >> 1) & 7);
+    const int n = n0 + row;
+    b_base[i] = n < p.N ? (int)((int64_t)n * 9 * p.Cin * ES) + ck * 16 : (int)kOOB;
+  }
+  auto issue_w = [&](int chunk, int tap, int stage) {
+    const int kb = tap * p.Cin * ES + chunk * 128;
+#pragma unroll
+    for (int i = 0; i < LB; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(sB + stage * (BN * 128) + (i * NW + wave) * 1024),
+                                               16, (uint32_t)b_base[i] + (uint32_t)kb, 0, 0, 0);
+  };
+
+  // ---- GroupNorm pass: the tile's scale/shift rows live in LDS ([2][NI][Cin] f32, staged
+  // once); a thread owns pieces id = tid + k*NT (halo row id>>3, slot id&7).  All pieces
+  // are read, then transformed, then written back: no serial read-modify-write chain.
+  float* sS = (float*)(smem + 2 * HB + 2 * BN * 128);
+  const int sS_half = p.ni * p.Cin;
+  int g_meta[MAXP];                               // (local image << 1) | in-image, per owned piece
+  if (p.a_scale) {
+    for (int idx = tid; idx < sS_half; idx += NT) {
+      const int img = idx / p.Cin, c = idx - img * p.Cin, b = b0 + img;
+      sS[idx] = b < p.B ? p.a_scale[(int64_t)b * p.Cin + c] : 0.f;
+      sS[sS_half + idx] = b < p.B ? p.a_shift[(int64_t)b * p.Cin + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int id = tid + k * NT, h = id >> 3;
+      int meta = 0;
+      if (h < p.hr) {
+        const int img = h / p.hs, rem = h - img * p.hs;
+        const int hy = rem / p.hs_w, hx = rem - hy * p.hs_w;
+        const int sy = sy0 + hy, sx = sx0 + hx, b = b0 + img;
+        if (b < p.B && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W) meta = (img << 1) | 1;
+      }
+      g_meta[k] = meta;
+    }
+    __syncthreads();
+  }
+  auto normalise_halo = [&](int chunk, int buf) {
+    char* base = sA + buf * HB;
+    u32x4 raw[MAXP];
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int id = tid + k * NT;
+      if (g_meta[k] & 1) raw[k] = *(const u32x4*)(base + (id >> 3) * 128 + (id & 7) * 16);
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int id = tid + k * NT;
+      if (g_meta[k] & 1) {
+        const int h = id >> 3, slot = id & 7;
+        const int ck = slot ^ ((h >> 1) & 7);      // which channel chunk sits in this slot
+        const float* sc = sS + (g_meta[k] >> 1) * p.Cin + chunk * (8 * EPC) + ck * EPC;
+        const float* sh = sc + sS_half;
+        float f[EPC];
+        chunk_to_f32(raw[k], f, T());
+#pragma unroll
+        for (int e4 = 0; e4 < EPC / 4; ++e4) {
+          const f32x4 s4 = *(const f32x4*)(sc + e4 * 4), t4 = *(const f32x4*)(sh + e4 * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float y = f[e4 * 4 + e] * s4[e] + t4[e];
+            f[e4 * 4 + e] = p.a_silu ? silu_f(y) : y;
+          }
+        }
+        raw[k] = f32_to_chunk(f, T());
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int id = tid + k * NT;
+      if (g_meta[k] & 1) *(u32x4*)(base + (id >> 3) * 128 + (id & 7) * 16) = raw[k];
+    }
+  };
+
+  // ---- A fragment geometry: lane lr <-> output pixel wm*WTM + i*32 + lr of the tile ------
+  const int lr = lane & 31, lh = lane >> 5;
+  int f_ib[TM], f_ty[TM], f_tx[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int pr = wm * WTM + i * 32 + lr;
+    const int img = pr >> p.log_thw, q = pr & ((1 << p.log_thw) - 1);
+    f_ib[i] = img * p.hs;
+    f_ty[i] = q >> p.log_tw;
+    f_tx[i] = q & (p.tw - 1);
+  }
+  const int swB = (lr >> 1) & 7;
+  int offB[4];
+#pragma unroll
+  for (int kg = 0; kg < 4; ++kg) offB[kg] = (wn * WTN + lr) * 128 + (((kg * 2 + lh) ^ swB) << 4);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // ---- main loop --------------------------------------------------------------------------
+#pragma unroll
+  for (int s = 0; s < 8; ++s) issue_halo(0, s, 0);
+  issue_w(0, 0, 0);
+  const int nk = p.nchunks * 9;
+  int chunk = 0, tap = 0;
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int abuf = chunk & 1;
+    if (tap == 0 && p.a_scale) {                  // uniform
+      normalise_halo(chunk, abuf);
+      __syncthreads();
+    }
+    if (t + 1 < nk) {
+      const int nt = tap == 8 ? 0 : tap + 1, nc = tap == 8 ? chunk + 1 : chunk;
+      issue_w(nc, nt, (t + 1) & 1);
+    }
+    if (tap < 8 && chunk + 1 < p.nchunks) issue_halo(chunk + 1, tap, abuf ^ 1);
+
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const char* cA = sA + abuf * HB;
+    const char* cB = sB + (t & 1) * (BN * 128);
+    u32x4 fa[4][TM], fb[4][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int hrow;
+      if constexpr (UPS) hrow = f_ib[i] + (((f_ty[i] + kh - 1) >> 1) + 1) * p.hs_w + ((f_tx[i] + kw - 1) >> 1) + 1;
+      else hrow = f_ib[i] + (f_ty[i] + kh) * p.hs_w + f_tx[i] + kw;
+      const int sw = (hrow >> 1) & 7;
+      const char* rp = cA + hrow * 128;
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) fa[kg][i] = *(const u32x4*)(rp + (((kg * 2 + lh) ^ sw) << 4));
+    }
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[kg][j] = *(const u32x4*)(cB + offB[kg] + j * 32 * 128);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) mma32h(acc[i][j], fa[kg][i], fb[kg][j], T());
+    __builtin_amdgcn_s_setprio(0);
+    if (tap == 8) { tap = 0; ++chunk; } else ++tap;
+  }
+  __syncthreads();
+
+  // ---- epilogue through LDS (f32 tile [BM][BN]), 8-column vector pieces --------------------
+  float* sC = (float*)smem;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        sC[row * BN + wn * WTN + j * 32 + lr] = acc[i][j][r];
+      }
+  __syncthreads();
+  constexpr int PCOLS = BN / 8;
+  for (int c = tid; c < BM * PCOLS; c += NT) {
+    const int row = c / PCOLS, pc = c - row * PCOLS;
+    const int img = row >> p.log_thw, q = row & ((1 << p.log_thw) - 1);
+    const int b = b0 + img, oy = y0 + (q >> p.log_tw), ox = x0 + (q & (p.tw - 1));
+    const int ncol = n0 + pc * 8;
+    if (b >= p.B || ncol >= p.N) continue;
+    const int m = (b * p.OH + oy) * p.OW + ox;
+    float v[8];
+    {
+      const f32x4 x0v = *(const f32x4*)(sC + row * BN + pc * 8);
+      const f32x4 x1v = *(const f32x4*)(sC + row * BN + pc * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] = x0v[e]; v[4 + e] = x1v[e]; }
+    }
+    if (p.bias) {
+      const f32x4 b0v = *(const f32x4*)(p.bias + ncol), b1v = *(const f32x4*)(p.bias + ncol + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += b0v[e]; v[4 + e] += b1v[e]; }
+    }
+    if (p.addend) {
+      const float* ad = p.addend + (int64_t)(m / p.add_rows) * p.add_ld + ncol;
+      const f32x4 a0 = *(const f32x4*)ad, a1 = *(const f32x4*)(ad + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+    }
+    const int64_t ooff = (int64_t)m * p.ldc + ncol;
+    const int64_t roff = (int64_t)m * p.ldr + ncol;
+    if (p.out_dtype == LDM_BF16) {
+      if (p.residual) {
+        float rr[8];
+        chunk_to_f32(*(const u32x4*)((const bf16_t*)p.residual + roff), rr, bf16_t());
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+      }
+      *(u32x4*)((bf16_t*)p.out + ooff) = f32_to_chunk(v, bf16_t());
+    } else {
+      if (p.residual) {
+        const f32x4 r0 = *(const f32x4*)((const float*)p.residual + roff);
+        const f32x4 r1 = *(const f32x4*)((const float*)p.residual + roff + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+      }
+      f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+      *(f32x4*)((float*)p.out + ooff) = o0;
+      *(f32x4*)((float*)p.out + ooff + 4) = o1;
+    }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+struct HaloCfg { int bm, bn, nw; };
+constexpr HaloCfg kHalo[4] = {{0, 0, 0}, {256, 128, 8}, {128, 128, 4}, {128, 64, 4}};
+
+int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_one(const HaloArgs& a, bool ups, dim3 grid, size_t shm, hipStream_t s) {
+  auto k0 = conv_halo_kernel<T, BM, BN, WM, WN, false>;
+  auto k1 = conv_halo_kernel<T, BM, BN, WM, WN, true>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[ups]) {   // allow > 64 KiB of dynamic LDS (not a stream operation: capture-safe)
+    if (hipFuncSetAttribute(ups ? (const void*)k1 : (const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      (void)hipGetLastError();
+      return -1;
+    }
+    attr_set[ups] = true;
+  }
+  if (ups) hipLaunchKernelGGL(k1, grid, dim3(WM * WN * 64), shm, s, a);
+  else hipLaunchKernelGGL(k0, grid, dim3(WM * WN * 64), shm, s, a);
+  return 0;
+}
+
+}  // namespace
+
+// Geometry + eligibility for a halo configuration; fills `a` and the LDS size.
+static bool halo_plan(const ldm_gemm_params* p, int cfg, HaloArgs* a, size_t* shm) {
+  const HaloCfg c = kHalo[cfg];
+  const int esize = p->dtype == LDM_BF16 ? 2 : 4;
+  const int osize = p->out_dtype == LDM_BF16 ? 2 : 4;
+  (void)osize;
+  if (!p->conv || p->stride != 1 || p->batch != 1 || p->act != LDM_ACT_NONE) return false;
+  const int OH = p->OH, OW = p->OW;
+  int th, tw, ni;
+  if (OH * OW >= c.bm) {
+    tw = OW < 32 ? OW : 32;
+    th = c.bm / tw;
+    ni = 1;
+    if (OW % tw || OH % th) return false;
+  } else {
+    if (c.bm % (OH * OW)) return false;
+    ni = c.bm / (OH * OW); th = OH; tw = OW;
+  }
+  if (!is_pow2(tw) || !is_pow2(th * tw) || th * tw * ni != c.bm) return false;
+  if (p->upsample && ((th & 1) || (tw & 1))) return false;
+  const int ths = p->upsample ? th / 2 : th, tws = p->upsample ? tw / 2 : tw;
+  const int hs_w = tws + 2, hs = (ths + 2) * hs_w, hr = ni * hs;
+  if (hr > 8 * c.nw * 8) return false;                 // eight staging slots of nw*8 rows
+  if (hr * 8 > 8 * c.nw * 64) return false;            // GroupNorm pass: <= 8 pieces per thread
+  const int hr_pad = (hr + 7) / 8 * 8;
+  size_t need = (size_t)2 * hr_pad * 128 + (size_t)2 * c.bn * 128;
+  if (p->a_scale) {
+    const size_t ss = (size_t)2 * ni * p->Cin * 4;   // the tile's scale/shift rows
+    if (ss > 20 * 1024) return false;
+    need += ss;
+  }
+  const size_t epi = (size_t)c.bm * c.bn * 4;
+  if (need < epi) need = epi;
+  if (need > 160 * 1024) return false;
+  // vector epilogue requirements
+  auto al = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+  if (p->ldc_n != 1 || p->N % 8 || p->ldc_m % 8 || !al(p->out)) return false;
+  if (p->residual && (p->ldr % 8 || !al(p->residual))) return false;
+  if (p->bias && !al(p->bias)) return false;
+  if (p->addend && (!al(p->addend) || p->add_ld % 4)) return false;
+  if (p->a_scale && (!al(p->a_scale) || !al(p->a_shift) || p->Cin % 4)) return false;
+  memset(a, 0, sizeof(*a));
+  a->a = (const char*)p->a; a->w = (const char*)p->w; a->bias = p->bias; a->addend = p->addend;
+  a->residual = (const char*)p->residual; a->out = (char*)p->out;
+  a->a_scale = p->a_scale; a->a_shift = p->a_shift;
+  a->lda = p->lda; a->ldr = p->ldr; a->ldc = p->ldc_m; a->add_ld = p->add_ld;
+  a->a_bytes = (uint32_t)((((int64_t)p->B * p->H * p->W - 1) * p->lda + p->Cin) * esize);
+  a->w_bytes = (uint32_t)((int64_t)p->N * p->K * esize);
+  a->B = p->B; a->H = p->H; a->W = p->W; a->Cin = p->Cin; a->OH = OH; a->OW = OW; a->N = p->N; a->M = p->M;
+  a->add_rows = p->add_rows > 0 ? p->add_rows : 1;
+  a->th = th; a->tw = tw; a->ni = ni; a->log_tw = ilog2(tw); a->log_thw = ilog2(th * tw);
+  a->tiles_x = OW / tw;
+  a->tiles_per_group = (OH / th) * (OW / tw);
+  a->tiles_m = ((p->B + ni - 1) / ni) * a->tiles_per_group;
+  a->tiles_n = (p->N + c.bn - 1) / c.bn;
+  a->hs_w = hs_w; a->hs = hs; a->hr = hr; a->hr_pad = hr_pad;
+  a->nchunks = p->Cin * esize / 128;
+  a->a_silu = p->a_silu; a->out_dtype = p->out_dtype;
+  *shm = need;
+  return true;
+}
+
+// Called by ldm_gemm.  Returns 1 if the launch was done by a halo kernel, 0 if the caller
+// must use the implicit-GEMM path, < 0 on error.  `cfg` 0 = choose.
+static int halo_pick(const ldm_gemm_params* p, int cfg, HaloArgs* out_a, size_t* out_shm) {
+  HaloArgs a;
+  size_t shm = 0;
+  int pick = 0;
+  if (cfg > 0) {
+    if (cfg > 3 || !halo_plan(p, cfg, &a, &shm)) return 0;
+    pick = cfg;
+  } else {
+    // Cost model calibrated with tools/gemm_bench.py (MI355X, bf16): a launch runs in rounds
+    // of (256 CUs x resident workgroups); a round-step costs kStep[c] when a workgroup has
+    // the CU to itself and ~1.27x / 1.6x that with 2 / 3 co-resident workgroups.
+    static const double kStep[4] = {0, 0.86, 0.60, 0.45};
+    static const double kCo[4] = {0, 1.0, 1.27, 1.6};
+    const double f32x = p->dtype == LDM_F32 ? 8.0 : 1.0;
+    double best = 1e30;
+    for (int c = 1; c <= 3; ++c) {
+      HaloArgs t; size_t s2;
+      if (!halo_plan(p, c, &t, &s2)) continue;
+      int resident = (int)((160 * 1024) / s2);
+      resident = resident < 1 ? 1 : (resident > 3 ? 3 : resident);
+      const double tiles = (double)t.tiles_m * t.tiles_n;
+      // The halo kernel has no split-K: a grid that cannot fill the chip is left to the
+      // implicit-GEMM path (and its separate GroupNorm apply), which measures faster there.
+      const char* mt = getenv("LDM_HALO_MIN_TILES");   // test hook: exercise the path on tiny shapes
+      const int min_tiles = mt ? atoi(mt) : 256;
+      if (tiles < min_tiles) continue;
+      const double rounds = (double)(int64_t)((tiles + 256.0 * resident - 1) / (256.0 * resident));
+      const double us = rounds * (t.nchunks * 9 + 10) * kStep[c] * kCo[resident] * f32x;
+      if (us < best) { best = us; pick = c; a = t; shm = s2; }
+    }
+    if (!pick) return 0;
+  }
+  *out_a = a;
+  *out_shm = shm;
+  return pick;
+}
+
+extern "C" int ldm_conv_prologue_supported(const ldm_gemm_params* p) {
+  if (!p || !p->conv || p->stride != 1 || p->split_k > 1 || getenv("LDM_NO_HALO")) return 0;
+  if (!(p->tile == 0 || p->tile > 10)) return 0;
+  // plan WITH the prologue's LDS (scale/shift rows) so the answer matches the launch
+  ldm_gemm_params q = *p;
+  static const float dummy[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
+  if (!q.a_scale) { q.a_scale = dummy; q.a_shift = dummy; }
+  HaloArgs a;
+  size_t shm;
+  return halo_pick(&q, q.tile > 10 ? q.tile - 10 : 0, &a, &shm) > 0 ? 1 : 0;
+}
+
+int ldm_conv_halo_try(const ldm_gemm_params* p, int cfg, void* stream) {
+  HaloArgs a;
+  size_t shm = 0;
+  const int pick = halo_pick(p, cfg, &a, &shm);
+  if (!pick) return 0;
+  const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n;
+  dim3 grid((unsigned)nblk);
+  hipStream_t s = (hipStream_t)stream;
+  const bool ups = p->upsample != 0;
+  int r;
+  if (p->dtype == LDM_BF16) {
+    if (pick == 1) r = launch_one<bf16_t, 256, 128, 4, 2>(a, ups, grid, shm, s);
+    else if (pick == 2) r = launch_one<bf16_t, 128, 128, 2, 2>(a, ups, grid, shm, s);
+    else r = launch_one<bf16_t, 128, 64, 2, 2>(a, ups, grid, shm, s);
+  } else {
+    if (pick == 1) r = launch_one<float, 256, 128, 4, 2>(a, ups, grid, shm, s);
+    else if (pick == 2) r = launch_one<float, 128, 128, 2, 2>(a, ups, grid, shm, s);
+    else r = launch_one<float, 128, 64, 2, 2>(a, ups, grid, shm, s);
+  }
+  if (r < 0) { ldm_set_error("ldm_gemm(halo): cannot raise the dynamic LDS limit"); return LDM_ERR_LAUNCH; }
+  const int st = ldm_launch_status("ldm_gemm(conv halo)");
+  return st == LDM_OK ? 1 : st;
+}

@@ -619,6 +619,18 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   }
   LDM_CHECK_ARG(p->ldc_n == 1 || p->ldc_m == 1, "ldm_gemm: one of ldc_m / ldc_n must be 1");
 
+  // stride-1 convolutions with a GroupNorm prologue (or a forced halo tile): halo-staged
+  // kernel of conv_halo.hip.  Without a prologue the implicit-GEMM kernel measures equal or
+  // faster, so it stays the default.
+  if (p->conv && p->stride == 1 && ((p->tile == 0 && p->a_scale) || p->tile > 10) && p->split_k <= 1 &&
+      !getenv("LDM_NO_HALO")) {
+    const int r = ldm_conv_halo_try(p, p->tile > 10 ? p->tile - 10 : 0, stream);
+    if (r == 1) return LDM_OK;
+    if (r < 0) return r;
+  }
+  LDM_CHECK_ARG(!p->a_scale, "ldm_gemm: the a_scale/a_shift prologue needs the stride-1 halo conv path "
+                             "(shape not eligible: use ldm_groupnorm_apply + a plain conv)");
+
   int cfg, split;
   choose(p, esize, &cfg, &split);
   if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2, "ldm_gemm: GEGLU needs tile 1 or 2");

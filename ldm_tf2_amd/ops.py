@@ -130,11 +130,8 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
   return out
 
 
-def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residual=None,
-            tile=0, split_k=0):
-  """3x3 convolution, NHWC, pad 1 (Keras SAME for stride 1; the U-Net's explicit
-  pad(1,1)+VALID for stride 2), optional fused nearest-2x upsample of the input.
-  x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout]."""
+def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale, a_shift,
+                 a_silu):
   B, H, W, Cin = x.shape
   Cout = wt.shape[0]
   hs, ws_ = (2 * H, 2 * W) if upsample else (H, W)
@@ -158,8 +155,30 @@ def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residu
   p.stride, p.upsample = stride, int(bool(upsample))
   p.act, p.dtype, p.out_dtype, p.alpha = ACT_NONE, code(x.dtype), code(out.dtype), 1.0
   p.tile, p.split_k = tile, split_k
+  if a_scale is not None:
+    assert tuple(a_scale.shape) == (B, Cin) and tuple(a_shift.shape) == (B, Cin)
+    assert a_scale.is_contiguous() and a_shift.is_contiguous()
+    p.a_scale, p.a_shift = _ptr(_f32(a_scale, "a_scale")), _ptr(_f32(a_shift, "a_shift"))
+    p.a_silu = int(bool(a_silu))
+  return p
+
+
+def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residual=None,
+            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False):
+  """3x3 convolution, NHWC, pad 1 (Keras SAME for stride 1; the U-Net's explicit
+  pad(1,1)+VALID for stride 2), optional fused nearest-2x upsample of the input and optional
+  GroupNorm(+SiLU) prologue on the input (a_scale/a_shift [B,Cin] from groupnorm_scale_shift).
+  x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout]."""
+  p = _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale,
+                   a_shift, a_silu)
   _gemm(p, x.device)
   return out
+
+
+def conv3x3_prologue_supported(x, wt, out, stride=1, upsample=False, tile=0):
+  """True if this convolution runs on the halo path, i.e. accepts the GroupNorm prologue."""
+  p = _conv_params(x, wt, out, None, stride, upsample, None, None, tile, 0, None, None, False)
+  return bool(lib.ldm_conv_prologue_supported(C.byref(p)))
 
 
 def bmm_nt(a, w, out, alpha=1.0, bias=None, transposed_out=False, tile=0):
@@ -215,6 +234,24 @@ def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None):
                                 nch, float(eps), int(bool(silu)), dt, _stream()),
         "ldm_groupnorm_apply")
   return out
+
+
+def groupnorm_scale_shift(x, gamma, beta, scale, shift, eps, groups=32, partial=None):
+  """GroupNorm statistics of x [B,H,W,C] folded into scale/shift [B,C] (float32) for a
+  consumer that normalises on the fly (conv3x3's a_scale / a_shift)."""
+  B, C = x.shape[0], x.shape[-1]
+  HW = x.numel() // (B * C)
+  nch = lib.ldm_groupnorm_nchunks(B, HW, C)
+  if partial is None:
+    partial = torch.empty(B * nch * groups * 2, dtype=torch.float32, device=x.device)
+  assert partial.numel() >= B * nch * groups * 2
+  assert tuple(scale.shape) == (B, C) and tuple(shift.shape) == (B, C)
+  check(lib.ldm_groupnorm_partial(_ptr(x), row_ld(x), _ptr(partial), B, HW, C, groups, nch,
+                                  code(x.dtype), _stream()), "ldm_groupnorm_partial")
+  check(lib.ldm_groupnorm_finalize(_ptr(partial), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
+                                   _ptr(_f32(scale, "scale")), _ptr(_f32(shift, "shift")), B, HW, C,
+                                   groups, nch, float(eps), _stream()), "ldm_groupnorm_finalize")
+  return scale, shift
 
 
 def layernorm(x, gamma, beta, out, eps=1e-5):

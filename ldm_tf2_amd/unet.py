@@ -88,7 +88,14 @@ class UNet:
   def __init__(self, model_channels=320, out_channels=4, num_blocks=2,
                attention_resolutions=(4, 2, 1), dropout_rate=0.1, channel_mult=(1, 2, 4, 4),
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
-               context_dim=1280, init="keras", seed=2):
+               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False):
+    # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
+    # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
+    # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
+    # the VALU), which costs more than the one streaming pass it removes.  Kept as an
+    # option (parity-tested) for wider-N tiles in a later round.
+    self.fuse_groupnorm = fuse_groupnorm
+    self._fuse_cache = {}
     self._model_channels = model_channels
     self._out_channels = out_channels
     self._num_blocks = num_blocks
@@ -186,20 +193,36 @@ class UNet:
     self._ctx_rows = R
 
   # ---- blocks ------------------------------------------------------------------------------
+  def _gn_conv(self, x, gn, conv, out, **kw):
+    """conv3x3(SiLU(GroupNorm(x))) (unet.py:383-384,390-392).  On large feature maps the
+    normalisation is folded into the halo-staged conv (applied once per element in LDS);
+    otherwise a separate normalise pass feeds the implicit-GEMM conv."""
+    B_, dt = self.buf, self.dtype
+    R, cin = x.shape[0], x.shape[-1]
+    key = ("gnconv", tuple(x.shape), x.stride(), tuple(out.shape), out.stride())
+    fused = self._fuse_cache.get(key)
+    if fused is None:
+      fused = self.fuse_groupnorm and ops.conv3x3_prologue_supported(x, conv[0], out)
+      self._fuse_cache[key] = fused
+    if fused:
+      sc = B_.get("gn_scale", (R, cin), torch.float32)
+      sh = B_.get("gn_shift", (R, cin), torch.float32)
+      ops.groupnorm_scale_shift(x, gn[0], gn[1], sc, sh, GN_EPS_RES, partial=self._gnp)
+      return ops.conv3x3(x, conv[0], out, bias=conv[1], a_scale=sc, a_shift=sh, a_silu=True, **kw)
+    t0 = B_.get("gn", tuple(x.shape), dt)
+    ops.groupnorm(x, gn[0], gn[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
+    return ops.conv3x3(t0, conv[0], out, bias=conv[1], **kw)
+
   def _res(self, r, x, tall, out):
     B_, dt = self.buf, self.dtype
     R, h, w, _ = x.shape
-    t0 = B_.get("gn", (R, h, w, r.cin), dt)
-    ops.groupnorm(x, r.gn1[0], r.gn1[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
     h1 = B_.get("h1", (R, h, w, r.cout), dt)
-    ops.conv3x3(t0, r.conv1[0], h1, bias=r.conv1[1], addend=tall[:, r.temb_off:r.temb_off + r.cout])
-    t1 = B_.get("gn", (R, h, w, r.cout), dt)
-    ops.groupnorm(h1, r.gn2[0], r.gn2[1], t1, GN_EPS_RES, silu=True, partial=self._gnp)
+    self._gn_conv(x, r.gn1, r.conv1, h1, addend=tall[:, r.temb_off:r.temb_off + r.cout])
     res = x
     if r.shortcut is not None:
       res = B_.get("sc", (R, h, w, r.cout), dt)
       ops.linear(x, r.shortcut[0], res, bias=r.shortcut[1])
-    ops.conv3x3(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
+    self._gn_conv(h1, r.gn2, r.conv2, out, residual=res)
     return out
 
   def _st(self, st, x, out):
