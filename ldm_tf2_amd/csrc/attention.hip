@@ -38,7 +38,6 @@ __device__ __forceinline__ void mma32a(f32x16& acc, const u32x4& a, const u32x4&
 
 template <typename T> struct AttnTraits;
 template <> struct AttnTraits<bf16_t> {
-  static constexpr int KT = 64;   // keys per LDS tile
   static constexpr int NPC = 2;   // P chunks (k-steps) per 32-key sub-tile
   __device__ static __forceinline__ int kappa(int i) {  // swap bits 2 and 3
     return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1);
@@ -52,7 +51,6 @@ template <> struct AttnTraits<bf16_t> {
   }
 };
 template <> struct AttnTraits<float> {
-  static constexpr int KT = 32;
   static constexpr int NPC = 4;
   __device__ static __forceinline__ int kappa(int i) { return i; }
   __device__ static __forceinline__ u32x4 pchunk(const f32x16& s, int pc) {
@@ -63,21 +61,27 @@ template <> struct AttnTraits<float> {
   }
 };
 
-template <typename T, int SP>
+// SP = padded head size (multiple of 16: the padding lives in zero weight rows), KT = keys
+// per LDS tile.  The O^T accumulator is built from 32-row MFMA tiles, so when SP is not a
+// multiple of 32 the last tile's upper rows read unstaged LDS: they only ever feed output
+// rows >= SP, which are never stored.
+template <typename T, int SP, int KT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
   using TR = AttnTraits<T>;
   constexpr int EPC = Elem<T>::kPerChunk;
-  constexpr int KT = TR::KT, NPC = TR::NPC;
+  constexpr int NPC = TR::NPC;
   constexpr int NSUB = KT / 32;
   constexpr int DCH = SP / EPC;                 // 16-byte chunks per K row
+  constexpr int VCH = KT / EPC;                 // 16-byte chunks per V^T row
   constexpr int NKG = SP * (int)sizeof(T) / 32; // 32-byte k groups over the head dim
-  constexpr int ND = SP / 32;                   // O^T tiles
+  constexpr int ND = (SP + 31) / 32;            // O^T tiles
   constexpr int KRS = SP * (int)sizeof(T) + 16; // padded LDS row strides (odd * 16 B)
   constexpr int VRS = KT * (int)sizeof(T) + 16;
   constexpr int CK = (KT * DCH + 255) / 256;
-  constexpr int CV = (SP * 8 + 255) / 256;
+  constexpr int CV = (SP * VCH + 255) / 256;
+  static_assert(SP % 16 == 0 && KT % 32 == 0 && (SP * (int)sizeof(T)) % 32 == 0, "attention tile");
 
-  __shared__ __attribute__((aligned(16))) char smem[KT * KRS + SP * VRS];
+  __shared__ __attribute__((aligned(16))) char smem[KT * KRS + ND * 32 * VRS];
   char* sK = smem;
   char* sV = smem + KT * KRS;
 
@@ -121,9 +125,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < CV; ++i) {
       const int id = tid + i * 256;
-      const int dim = id >> 3, kc = id & 7;
+      const int dim = id / VCH, kc = id - dim * VCH;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (id < SP * 8 && kt0 + kc * EPC < p.ldvt)
+      if (id < SP * VCH && kt0 + kc * EPC < p.ldvt)
         v = *(const u32x4*)(Vt + (int64_t)dim * p.ldvt + kt0 + kc * EPC);
       rv[i] = v;
     }
@@ -138,8 +142,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
     for (int i = 0; i < CV; ++i) {
       const int id = tid + i * 256;
-      const int dim = id >> 3, kc = id & 7;
-      if (id < SP * 8) *(u32x4*)(sV + dim * VRS + kc * 16) = rv[i];
+      const int dim = id / VCH, kc = id - dim * VCH;
+      if (id < SP * VCH) *(u32x4*)(sV + dim * VRS + kc * 16) = rv[i];
     }
   };
 
@@ -233,6 +237,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         const int dim = d * 32 + 8 * r4 + 4 * lh;
+        if (dim >= SP) continue;                  // rows of the partial last tile
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = o[d][r4 * 4 + e] * inv;
@@ -249,13 +254,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
 
 template <typename T>
 int launch_attn(const AttnArgs& a, int Sp, dim3 grid, hipStream_t s) {
+  // keys per tile: 128 for bf16 heads <= 64 (half the barriers), 64 above (register budget);
+  // float32 tiles are half as many keys for the same LDS bytes
+  constexpr bool H = sizeof(T) == 2;
+#define ATTN_CASE(SPV, KTB, KTF)                                                                 \
+  case SPV:                                                                                      \
+    hipLaunchKernelGGL((attn_kernel<T, SPV, H ? KTB : KTF>), grid, dim3(256), 0, s, a);          \
+    break;
   switch (Sp) {
-    case 32: hipLaunchKernelGGL((attn_kernel<T, 32>), grid, dim3(256), 0, s, a); break;
-    case 64: hipLaunchKernelGGL((attn_kernel<T, 64>), grid, dim3(256), 0, s, a); break;
-    case 96: hipLaunchKernelGGL((attn_kernel<T, 96>), grid, dim3(256), 0, s, a); break;
-    case 160: hipLaunchKernelGGL((attn_kernel<T, 160>), grid, dim3(256), 0, s, a); break;
+    ATTN_CASE(32, 128, 64)
+    ATTN_CASE(48, 64, 32)
+    ATTN_CASE(64, 64, 32)
+    ATTN_CASE(80, 64, 32)
+    ATTN_CASE(96, 64, 32)
+    ATTN_CASE(160, 64, 32)
     default: return -1;
   }
+#undef ATTN_CASE
   return 0;
 }
 
@@ -283,6 +298,6 @@ extern "C" int ldm_attention(const void* q, int64_t ldq, int64_t q_bs, const voi
   dim3 grid((Tq + 127) / 128, heads, batch);
   hipStream_t s = (hipStream_t)stream;
   int r = dtype == LDM_BF16 ? launch_attn<bf16_t>(a, Sp, grid, s) : launch_attn<float>(a, Sp, grid, s);
-  LDM_CHECK_ARG(r == 0, "ldm_attention: unsupported padded head size Sp=%d (32/64/96/160)", Sp);
+  LDM_CHECK_ARG(r == 0, "ldm_attention: unsupported padded head size Sp=%d (32/48/64/80/96/160)", Sp);
   return ldm_launch_status("ldm_attention");
 }

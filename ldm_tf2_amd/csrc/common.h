@@ -94,8 +94,23 @@ __device__ __forceinline__ u32x4 f32_to_chunk(const float (&f)[8], bf16_t) {
 __device__ __forceinline__ float silu_f(float x) {
   return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+// Exact-erf GELU (tf.nn.gelu default).  erf by Abramowitz & Stegun 7.1.26 (|abs err| <=
+// 1.5e-7, i.e. float32 rounding level) on the hardware rcp / exp2: ~14 VALU ops where the
+// device library's erff costs ~40 -- the GEGLU epilogue applies it to 4C values per token.
+__device__ __forceinline__ float erf_as_f(float x) {
+  const float ax = fabsf(x);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+  float poly = 1.061405429f;
+  poly = __builtin_fmaf(poly, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+  const float r = 1.0f - poly * t * e;
+  return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f));
 }
 
 // ---- wave reductions (wave = 64) ------------------------------------------

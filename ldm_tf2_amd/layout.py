@@ -18,7 +18,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-ATTN_SP = (32, 64, 96, 160)   # padded head sizes instantiated in attention.hip
+ATTN_SP = (32, 48, 64, 80, 96, 160)   # padded head sizes instantiated in attention.hip
 
 
 def padded_head(s: int) -> int:

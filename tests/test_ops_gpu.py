@@ -259,6 +259,9 @@ def _attn_case(dev, dtype, R, H, S, Tq, Tk, sp):
     dict(R=1, H=2, S=160, Tq=64, Tk=77, sp=160),
     dict(R=2, H=8, S=64, Tq=77, Tk=77, sp=64),
     dict(R=1, H=8, S=8, Tq=200, Tk=130, sp=32),
+    dict(R=2, H=8, S=40, Tq=256, Tk=256, sp=48),     # head sizes the U-Net uses: 40->48, 80->80
+    dict(R=2, H=8, S=40, Tq=192, Tk=77, sp=48),
+    dict(R=1, H=8, S=80, Tq=64, Tk=200, sp=80),
 ])
 def test_attention(dev, dtype, case):
   _attn_case(dev, dtype, **case)

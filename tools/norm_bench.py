@@ -59,7 +59,8 @@ def main():
     tot += ms * cnt
     print(f"  [{R},{hw:2d},{hw:2d},{C:4d}] x{cnt:2d}  {ms * 1e3:7.1f} us  {3 * x.numel() * 2 / ms / 1e6:7.0f} GB/s (2 reads + 1 write)")
   print("attention (self, cross)")
-  for T, Tk, S, sp, cnt in [(1024, 1024, 40, 64, 5), (1024, 77, 40, 64, 5), (256, 256, 80, 96, 5), (256, 77, 80, 96, 5),
+  for T, Tk, S, sp, cnt in [(1024, 1024, 40, 48, 5), (1024, 77, 40, 48, 5), (256, 256, 80, 80, 5), (256, 77, 80, 80, 5),
+                            (1024, 1024, 40, 64, 0), (256, 256, 80, 96, 0),
                             (64, 64, 160, 160, 5), (64, 77, 160, 160, 5), (16, 16, 160, 160, 1), (16, 77, 160, 160, 1)]:
     H = 8
     q = torch.randn(R, T, H * sp, device=dev).to(dt)
