@@ -507,8 +507,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
-constexpr TileCfg kTiles[5] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}};
-constexpr int kResident[5] = {0, 1, 2, 3, 5};   // workgroups per CU (LDS-limited: 2-stage ring)
+constexpr TileCfg kTiles[6] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {256, 128}};
+constexpr int kResident[6] = {0, 1, 2, 3, 5, 1};   // workgroups per CU (LDS-limited: 2-stage ring)
 
 template <typename T, int MODE>
 void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
@@ -516,6 +516,7 @@ void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
     case 1: hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2, MODE>), grid, dim3(512), 0, s, a); break;
     case 2: hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
+    case 5: hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;   // 4 waves x (128x64)
     default: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
   }
 }
@@ -534,8 +535,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // measured time one CU needs for one K-tile of that configuration with its resident
 // workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
-  static const double kStepUs[5] = {0, 0.82, 0.82, 0.75, 0.87};     // bf16, per round per K-tile (resident WGs co-running)
-  static const double kOverheadSteps[5] = {0, 8, 8, 7, 6};          // launch + prologue + epilogue, in K-tiles
+  static const double kStepUs[6] = {0, 0.82, 0.82, 0.75, 0.87, 0.82};     // bf16, per round per K-tile (resident WGs co-running)
+  static const double kOverheadSteps[6] = {0, 8, 8, 7, 6, 8};          // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
   const int bke = 128 / esize;
   const int ktiles = cdiv(p->K, bke);
@@ -543,9 +544,10 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   const double f32x = esize == 4 ? 8.0 : 1.0;   // f32 MFMA: 1/16 the rate at half the K per tile
   double best = 1e30;
   int best_cfg = 2, best_split = 1;
-  for (int c = 1; c <= 4; ++c) {
-    if (p->tile > 0 && p->tile <= 4 && c != p->tile) continue;
-    if (geglu && c > 2) continue;
+  for (int c = 1; c <= 5; ++c) {
+    if (p->tile > 0 && p->tile <= 5 && c != p->tile) continue;
+    if (c == 5 && p->tile != 5) continue;   // experimental: only when forced
+    if (geglu && c > 2 && c != 5) continue;
     const TileCfg t = kTiles[c];
     const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
     for (int split : kSplits) {
@@ -563,7 +565,7 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
     }
   }
   if (p->split_k > 0 && p->batch == 1) best_split = p->split_k;
-  if (p->tile > 0 && p->tile <= 4) best_cfg = p->tile;
+  if (p->tile > 0 && p->tile <= 5) best_cfg = p->tile;
   *cfg_out = best_cfg;
   *split_out = best_split;
 }
@@ -633,7 +635,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
 
   int cfg, split;
   choose(p, esize, &cfg, &split);
-  if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2, "ldm_gemm: GEGLU needs tile 1 or 2");
+  if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5, "ldm_gemm: GEGLU needs tile 1, 2 or 5");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.a = (const char*)p->a; a.w = (const char*)p->w; a.bias = p->bias; a.addend = p->addend;

@@ -271,6 +271,59 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
       sys.stdout.flush()
     return images
 
+  def ddim_p_sample_loop_progressive(self, cond_model_inputs, shape, guidance_scale=5.,
+                                     record_freq=5, x_T=None, noises=None, seed=0,
+                                     first_sample_index=0):
+    """Intended semantics of model_runners.py:511-575 (the reference version calls a method
+    that does not exist, :535, and returns three values to a caller unpacking two,
+    run_ldm_sampler.py:90 -- neither bug is reproduced).  Runs the same loop as
+    ddim_p_sample_loop and keeps, for each record slot r < N // record_freq, the sample and
+    the predicted x0 of the LAST step whose index // record_freq == r (the reference's
+    insert_mask overwrites a slot on every such step, :545-553), i.e. of index r*record_freq.
+    Returns (images [B,H,W,3], sample_progress [B,R,H,W,3], pred_x0_progress [B,R,H,W,3]),
+    all decoded with decode_first_stage."""
+    B, h, w, c = (int(s) for s in shape)
+    context = self._cond_stage_model(cond_model_inputs)
+    n = len(self._ddim_steps)
+    num_records = n // record_freq
+    if x_T is None:
+      x_T = normal_latents(seed, first_sample_index, B, (h, w, c))
+    xt = torch.as_tensor(np.asarray(x_T) if not isinstance(x_T, torch.Tensor) else x_T,
+                         dtype=torch.float32).to(self.device).contiguous()
+    self._alloc_state(B, h, w, c)
+    self._set_context(context)
+    noise_table = None
+    if self._eta != 0.:
+      if noises is None:
+        noises = np.stack([normal_latents(seed + 1 + i, first_sample_index, B, (h, w, c))
+                           for i in range(n)])
+      noise_table = torch.as_tensor(np.asarray(noises) if not isinstance(noises, torch.Tensor)
+                                    else noises, dtype=torch.float32).to(self.device).contiguous()
+    self._xt.copy_(xt)
+    self._x2[:B].copy_(xt)
+    self._x2[B:].copy_(xt)
+    self._index_dev.fill_(n - 1)
+    stride = 0 if noise_table is None else noise_table[0].numel()
+    sample_prog = torch.zeros(B, num_records, h, w, c, dtype=torch.float32, device=self.device)
+    x0_prog = torch.zeros_like(sample_prog)
+    pred_x0 = torch.empty_like(self._xt)
+    for index in range(n - 1, -1, -1):
+      self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps)
+      ops.cfg_ddim_update(self._eps, self._xt, self._xt, self._coef_dev, self._index_dev,
+                          guidance_scale, noise=noise_table, x_unet_out=self._x2, dec_index=True,
+                          clip_denoised=False, noise_index_stride=stride, pred_x0_out=pred_x0)
+      r = index // record_freq
+      if r < num_records:                      # later (smaller) indices overwrite the slot
+        sample_prog[:, r].copy_(self._xt)
+        x0_prog[:, r].copy_(pred_x0)
+    images = self.decode_first_stage(self._xt).clone()
+    flat = (B * num_records, h, w, c)
+    sp = self.decode_first_stage(sample_prog.reshape(flat).contiguous())
+    sp = sp.reshape(B, num_records, *sp.shape[1:]).clone()
+    xp = self.decode_first_stage(x0_prog.reshape(flat).contiguous())
+    xp = xp.reshape(B, num_records, *xp.shape[1:]).clone()
+    return images, sp, xp
+
   def last_loop_ms_per_step(self):
     """Device time of the last DDIM loop divided by its step count (synchronises)."""
     t0, t1, n = self._loop_events

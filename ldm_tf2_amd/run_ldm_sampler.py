@@ -12,8 +12,10 @@ sections `ldm_sampling`, `pre_ckpt_paths`, `cond_stage_model`, `autoencoder_kl|v
 Checkpoints: the reference restores TF checkpoints with expect_partial(), which
 silently leaves random-init weights when nothing matches.
 TF checkpoints cannot be read here; `pre_ckpt_paths` entries that point at an
-`.npz` of reference-layout arrays (weights.py names) are loaded, anything else
-falls back to seeded random init with a warning -- the same observable behaviour.
+`.npz` of reference-layout arrays (weights.py names) are loaded, and an extra key
+`pre_ckpt_paths.compvis` naming the original PyTorch checkpoint loads all three models
+through checkpoint.py; anything else falls back to seeded random init with a warning --
+the same observable behaviour.
 """
 from __future__ import annotations
 
@@ -42,7 +44,12 @@ def tensor_to_image(images):
   return out.cpu().numpy()
 
 
+_preloaded = {}
+
+
 def _load_weights(path, what):
+  if what in _preloaded:
+    return _preloaded.pop(what)
   if path and os.path.isfile(path) and path.endswith(".npz"):
     return dict(np.load(path))
   print(f"[WARN] no loadable checkpoint for {what} at {path!r}: using random-init weights "
@@ -52,8 +59,17 @@ def _load_weights(path, what):
 
 def build_from_config(config, dtype=torch.bfloat16, device="cuda:0", seed=2, use_graph=True,
                       verbose=True):
-  ck = config.get("pre_ckpt_paths", {})
-  transformer = TransformerModel(**config["cond_stage_model"], dtype=dtype, device=device, seed=seed,
+  ck = dict(config.get("pre_ckpt_paths", {}))
+  if ck.get("compvis"):
+    # one CompVis PyTorch checkpoint for all three models (checkpoint.py; what the
+    # reference reaches through convert_ckpt_pytorch_to_tf2.py + three TF checkpoints)
+    from .checkpoint import from_compvis_state_dict
+    sd = torch.load(ck["compvis"], map_location="cpu", weights_only=True)
+    sd = {k: v.float().numpy() for k, v in sd.get("state_dict", sd).items() if torch.is_tensor(v)}
+    ae_key = "autoencoder_kl" if config["ldm_sampling"]["autoencoder_type"] == "kl" else "autoencoder_vq"
+    loaded = from_compvis_state_dict(sd, config["unet"], config["cond_stage_model"], config[ae_key])
+    _preloaded.update(loaded)
+  transformer =TransformerModel(**config["cond_stage_model"], dtype=dtype, device=device, seed=seed,
                                  weights=_load_weights(ck.get("cond_stage_model"), "cond_stage_model"))
   unet = UNet(**config["unet"], dtype=dtype, device=device, seed=seed,
               context_dim=config["cond_stage_model"]["hidden_size"],
@@ -84,11 +100,19 @@ def main(argv=None):
   dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
   sampler = build_from_config(config, dtype=dtype)
   samp = config["ldm_sampling"]
-  if samp.get("sample_save_progress"):
-    raise NotImplementedError("progressive sampling is not on the hot path (the reference's "
-                              "implementation of it cannot run: SURVEY.md section 2 row 1b)")
   token_ids = get_token_ids(samp["text_prompt"], samp["latent_shape"][0], samp["vocab_dir"],
                             config["cond_stage_model"]["max_seq_len"])
+  if samp.get("sample_save_progress"):
+    # run_ldm_sampler.py:89-94 (with the reference's unpacking bug fixed: three results)
+    _, sample_prog, pred_x0_prog = sampler.ddim_p_sample_loop_progressive(
+        token_ids, samp["latent_shape"], samp["guidance_scale"], seed=args.seed)
+    for name, t in (("sample_prog.npy", sample_prog), ("pred_x0_prog.npy", pred_x0_prog)):
+      print(f"[INFO] Save progressive images to '{name}'...")
+      b, r = t.shape[0], t.shape[1]
+      # tensor_to_image normalises inputs[i] over everything but the batch axis (:19-22)
+      u8 = tensor_to_image(t.reshape(b, r * t.shape[2], t.shape[3], t.shape[4]))
+      np.save(name, u8.reshape(tuple(t.shape)))
+    return
   images = sampler.ddim_p_sample_loop(token_ids, samp["latent_shape"], samp["guidance_scale"],
                                       seed=args.seed)
   print(f"[INFO] Save generated images to '{args.out}'...")

@@ -449,6 +449,37 @@ def ddim_p_sample_loop(token_ids, x_T, weights, ldm, guidance_scale=5.,
                          force_quantize=(autoencoder_type == "vq"))
 
 
+def ddim_p_sample_loop_progressive(token_ids, x_T, weights, ldm, guidance_scale=5., record_freq=5,
+                                   noises=None, dtype=torch.float32, num_heads=8):
+  """Intended semantics of model_runners.py:511-575 (its two bugs -- the call to a
+  non-existent `ddim_p_sample`, :535, and the 3-vs-2 value unpacking in the CLI -- not
+  reproduced): slot r keeps sample / pred_x0 of the last step with index // record_freq == r
+  (insert_mask, :545-553); all three results are decoded (:565-570)."""
+  sched = make_schedule(ldm.get("num_steps", 1000), ldm.get("beta_start", 1e-4),
+                        ldm.get("beta_end", 2e-2), ldm.get("eta", 0.), ldm.get("num_ddim_steps", 50))
+  context = text_encoder(token_ids, weights["cond_stage_model"], dtype)
+  xt = _t(x_T, dtype)
+  n = len(sched["ddim_steps"])
+  num_records = n // record_freq
+  sp = torch.zeros((xt.shape[0], num_records) + tuple(xt.shape[1:]), dtype=dtype)
+  xp = torch.zeros_like(sp)
+  for index in range(n - 1, -1, -1):
+    noise = None if noises is None else noises[index]
+    xt, pred_x0, _ = ddim_sample(xt, context, index, sched, weights["unet"], guidance_scale, noise,
+                                 dtype, clip_denoised=False, num_heads=num_heads)
+    r = index // record_freq
+    if r < num_records:
+      sp[:, r] = xt
+      xp[:, r] = pred_x0
+  sf = ldm.get("scale_factor", 0.18215)
+  dec = lambda z: decoder_forward(z / sf, weights["autoencoder"], dtype)
+  b = xt.shape[0]
+  images = dec(xt)
+  spd = dec(sp.reshape((b * num_records,) + tuple(xt.shape[1:])))
+  xpd = dec(xp.reshape((b * num_records,) + tuple(xt.shape[1:])))
+  return images, spd.reshape((b, num_records) + tuple(spd.shape[1:])), xpd.reshape((b, num_records) + tuple(xpd.shape[1:]))
+
+
 def tensor_to_image(images):
   """run_ldm_sampler.py:18-25: per-image (x-min)/(max-min), *255, astype(uint8)
   (truncation)."""

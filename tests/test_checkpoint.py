@@ -1,0 +1,87 @@
+"""CompVis state_dict loader: name coverage, round trip, and that
+each layout transform means what the PyTorch module it came from computes (checked with
+torch.nn.functional against the oracle's reference-layout ops)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ldm_tf2_amd import checkpoint as C
+from ldm_tf2_amd import weights as W
+from oracle import ldm_oracle as O
+
+UCFG = dict(model_channels=32, channel_mult=(1, 2), num_blocks=1, context_dim=64)
+TCFG = dict(vocab_size=100, encoder_stack_size=2, hidden_size=64, size_per_head=8, filter_size=128, max_seq_len=16)
+ACFG = dict(channels=32, multipliers=(1, 2), num_blocks=1, latent_size=8)
+
+
+def test_rules_cover_the_full_size_manifests():
+  um, tm, am = W.unet_manifest(), W.transformer_manifest(), W.decoder_manifest()
+  ur, tr, ar = C.unet_rules(um), C.transformer_rules(tm), C.decoder_rules(am)
+  assert set(ur) == set(um) and set(tr) == set(tm) and set(ar) == set(am)
+  keys = [v[0] for r in (ur, tr, ar) for v in r.values()]
+  assert len(keys) == len(set(keys))                       # one checkpoint tensor per variable
+  # spot checks against the converter's own key strings (convert_ckpt_pytorch_to_tf2.py:88,:114,:266,:51)
+  assert ur["input_blocks/2/downsample/conv/kernel"][0] == "model.diffusion_model.input_blocks.3.0.op.weight"
+  assert ur["output_blocks/2/upsample/conv/kernel"][0] == "model.diffusion_model.output_blocks.2.1.conv.weight"
+  assert ur["output_blocks/5/upsample/conv/kernel"][0] == "model.diffusion_model.output_blocks.5.2.conv.weight"
+  assert ur["input_blocks/0/spatial_transformer/block/att_layer1/output/kernel"][0] == \
+      "model.diffusion_model.input_blocks.1.1.transformer_blocks.0.attn1.to_out.0.weight"
+  assert tr["encoder/layers/3/ffn/filter/kernel"][0] == "cond_stage_model.transformer.attn_layers.layers.7.1.net.0.0.weight"
+  assert ar["decoder/up/3/conv/kernel"][0] == "first_stage_model.decoder.up.3.upsample.conv.weight"
+  assert ar["decoder/up/12/residual/shortcut/kernel"][0] == "first_stage_model.decoder.up.0.block.0.nin_shortcut.weight"
+
+
+def test_round_trip_and_errors():
+  w = {"unet": W.init_weights(W.unet_manifest(**UCFG), 1, mode="random"),
+       "cond_stage_model": W.init_weights(W.transformer_manifest(**TCFG), 1, mode="random"),
+       "autoencoder": W.init_weights(W.decoder_manifest(**ACFG), 1, mode="random")}
+  sd = C.to_compvis_state_dict(w, UCFG, TCFG, ACFG)
+  back = C.from_compvis_state_dict(sd, UCFG, TCFG, ACFG)
+  for part in w:
+    assert set(back[part]) == set(w[part])
+    for k in w[part]:
+      assert np.array_equal(back[part][k], w[part][k]), k
+  # PyTorch-side shapes: conv OIHW, Linear [out, in]
+  assert sd["model.diffusion_model.input_blocks.0.0.weight"].shape == (32, 4, 3, 3)
+  assert sd["model.diffusion_model.time_embed.0.weight"].shape == (128, 32)
+  bad = dict(sd)
+  del bad["model.diffusion_model.out.2.bias"]
+  try:
+    C.from_compvis_state_dict(bad, UCFG, TCFG, ACFG)
+    raise AssertionError("missing key accepted")
+  except KeyError as e:
+    assert "out.2.bias" in str(e)
+  bad = dict(sd)
+  bad["model.diffusion_model.out.2.bias"] = np.zeros(7, np.float32)
+  try:
+    C.from_compvis_state_dict(bad, UCFG, TCFG, ACFG)
+    raise AssertionError("wrong shape accepted")
+  except ValueError:
+    pass
+
+
+def test_transforms_preserve_the_pytorch_module_semantics():
+  g = torch.Generator().manual_seed(0)
+  x = torch.randn(2, 6, 5, 5, generator=g)                                # NCHW
+  w = torch.randn(7, 6, 3, 3, generator=g)
+  ref = F.conv2d(x, w, padding=1).permute(0, 2, 3, 1)
+  got = O.conv2d(x.permute(0, 2, 3, 1), torch.from_numpy(C._conv(w.numpy())), None)
+  assert torch.allclose(ref, got, atol=1e-5)
+  w1 = torch.randn(7, 6, 1, 1, generator=g)                               # 1x1 conv -> dense
+  ref = F.conv2d(x, w1).permute(0, 2, 3, 1)
+  got = O.dense(x.permute(0, 2, 3, 1), torch.from_numpy(C._c1(w1.numpy())), None)
+  assert torch.allclose(ref, got, atol=1e-5)
+  t = torch.randn(3, 6, generator=g)
+  wl = torch.randn(9, 6, generator=g)
+  assert torch.allclose(F.linear(t, wl), O.dense(t, torch.from_numpy(C._lin(wl.numpy())), None), atol=1e-5)
+  # CrossAttention: q = to_q(x) -> 'b n (h d) -> (b h) n d'; out = to_out('(b h) n d -> b n (h d)')
+  heads, s, d = 4, 8, 24
+  xs = torch.randn(2, 5, d, generator=g)
+  wq = torch.randn(heads * s, d, generator=g)
+  q_pt = F.linear(xs, wq).reshape(2, 5, heads, s)
+  q_ref = torch.einsum("bnd,dhs->bnhs", xs, torch.from_numpy(C._split(heads)(wq.numpy())))
+  assert torch.allclose(q_pt, q_ref, atol=1e-5)
+  wo = torch.randn(d, heads * s, generator=g)
+  o_pt = F.linear(q_pt.reshape(2, 5, heads * s), wo)
+  o_ref = torch.einsum("bnhs,hsd->bnd", q_pt, torch.from_numpy(C._merge(heads)(wo.numpy())))
+  assert torch.allclose(o_pt, o_ref, atol=1e-4)

@@ -214,3 +214,24 @@ def test_ddim_loop_end_to_end(dev, dtype, eta, unet_w, txt_w, kl_w):
   # replaying the captured graph a second time reproduces the run
   got3 = s.ddim_p_sample_loop(ids, [B, 16, 16, 4], guidance_scale=5., x_T=x_T, noises=noises)
   assert torch.equal(got, got3)
+
+
+def test_progressive_sampling(dev, unet_w, txt_w, kl_w):
+  """intended semantics of ddim_p_sample_loop_progressive (float32, eta=1)."""
+  B, n, freq = 2, 10, 5
+  ldm = dict(LDM, eta=1.0)
+  ids = _ids(B)
+  g = np.random.default_rng(11)
+  x_T = g.standard_normal((B, 16, 16, 4)).astype(np.float32)
+  noises = g.standard_normal((n, B, 16, 16, 4)).astype(np.float32)
+  ri, rs, rx = O.ddim_p_sample_loop_progressive(ids, x_T, dict(unet=unet_w, autoencoder=kl_w, cond_stage_model=txt_w),
+                                                ldm, guidance_scale=5., record_freq=freq, noises=noises)
+  s = _build_sampler(dev, torch.float32, unet_w, txt_w, kl_w, ldm=ldm)
+  gi, gs, gx = s.ddim_p_sample_loop_progressive(ids, [B, 16, 16, 4], 5., record_freq=freq, x_T=x_T, noises=noises)
+  assert tuple(gs.shape) == (B, n // freq, 128, 128, 3) and tuple(gx.shape) == tuple(gs.shape)
+  check(gi, ri, torch.float32, "progressive: images", factor=5.0)
+  check(gs, rs, torch.float32, "progressive: samples", factor=5.0)
+  check(gx, rx, torch.float32, "progressive: pred_x0", factor=5.0)
+  # the final images equal the plain loop's
+  plain = s.ddim_p_sample_loop(ids, [B, 16, 16, 4], 5., x_T=x_T, noises=noises)
+  assert rel_err(plain, gi.cpu())[0] < 1e-5

@@ -106,6 +106,15 @@ def main():
       tot_gf += gf * cnt
       print(f"gemm M={R * T:6d} K={K:5d} N={N:5d} x{cnt:<3d}    {gf:8.1f} " +
             " ".join(f"{gf / ms:9.1f}" for ms in res) + f"   {min(res):.3f}")
+  if "conv" not in args.filter:
+    # GEGLU epilogue (value * exact-erf gelu(gate)): the three FF-in GEMMs with their real epilogue
+    for T, K, N in [(1024, 320, 2560), (256, 640, 5120), (64, 1280, 10240)]:
+      x = torch.randn(R * T, K, device=dev).to(dt)
+      w = (torch.randn(N, K, device=dev) * 0.02).to(dt)
+      b = torch.randn(N, device=dev)
+      out = torch.empty(R * T, N // 2, device=dev, dtype=dt)
+      ms = time_fn(lambda: ops.linear(x, w, out, bias=b, act=ops.ACT_GEGLU), args.rounds)
+      print(f"geglu M={R * T:6d} K={K:5d} N={N:5d}: {ms * 1e3:7.1f} us  {2.0 * R * T * N * K / 1e9 / ms:7.1f} TFLOP/s")
   print("total ms per U-Net step by tile:", {t: round(v, 2) for t, v in tot.items()},
         "best-per-shape:", round(tot_best, 2), f"=> {tot_gf / tot_best:.0f} TFLOP/s")
 
