@@ -37,8 +37,8 @@ sys.path.insert(0, ROOT)
 
 # algorithmic work (SURVEY.md section 8d / BASELINE.md section 2), GFLOP per U-Net row @32x32
 GF_UNET_ROW = {32: 182.48, 64: 809.54}
-GF_CONV_ROW = {32: 100.1}
-GF_GEMM_ROW = {32: 73.5}
+GF_CONV_ROW = {32: 100.1, 64: 400.4}
+GF_GEMM_ROW = {32: 73.5, 64: 279.3}   # 64: token GEMMs x4, context K/V unchanged
 GF_CTX_KV_ROW = 4.9          # cross-attention K/V GEMMs, hoisted out of the step (step-invariant)
 GF_DECODE = {32: 623.11, 64: 2518.3}
 GF_TEXT_ROW = 77.96
@@ -228,6 +228,10 @@ def main():
 
   if rank == 0:
     total_images = world * B * args.steps
+    key = (B, lat, args.ddim_steps, args.dtype)
+    which = {(16, 32, 200, "bf16"): "BASELINE configs[2]", (4, 32, 50, "f32"): "BASELINE configs[1]",
+             (8, 32, 200, "bf16"): "BASELINE configs[3]", (4, 64, 200, "f32"): "BASELINE configs[4]"}.get(
+                 key, "non-BASELINE variant")
     value = total_images / elapsed
     res = {
         "metric": "images/sec (256x256, 200 DDIM steps, CFG=5)" if (lat == 32 and args.ddim_steps == 200)
@@ -235,7 +239,7 @@ def main():
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": (f"txt2img-f8 1.45B LDM (BASELINE configs[2]): B={B}/GPU, latent {lat}x{lat}x4, "
+        "config": {"workload": (f"txt2img-f8 1.45B LDM ({which}): B={B}/GPU, latent {lat}x{lat}x4, "
                                 f"{args.ddim_steps} DDIM steps, CFG {args.guidance:g}, {args.dtype} U-Net/text/decoder, "
                                 "f32 scheduler, random-init weights, synthetic x_T + random BERT ids"),
                    "batch_per_gpu": B, "global_batch": world * B, "ddim_steps": args.ddim_steps,

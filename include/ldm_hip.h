@@ -104,6 +104,10 @@ typedef struct {
   const float* a_scale;
   const float* a_shift;
   int32_t a_silu;
+  /* conv: 0 = one zero row/column before the image (Keras SAME at stride 1; pad (1,1)+VALID at
+   * stride 2, unet.py:26-27); 1 = none before, one after -- the autoencoder's
+   * pad [[0,1],[0,1]] + stride-2 VALID downsample (autoencoder.py:133-136); stride 2 only. */
+  int32_t no_lead_pad;
 } ldm_gemm_params;
 
 int ldm_gemm(const ldm_gemm_params* p, void* stream);
@@ -207,6 +211,12 @@ int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const float* nois
 int ldm_post_quant(const float* latents, float scale_factor, const float* kernel_io,
                    const float* bias, void* out, int out_dtype, int64_t pixels, int C,
                    void* stream);
+
+/* DiagonalGaussian.sample / .mode (distribution.py:15-25,50): moments [pixels][2C] float32 =
+ * (mean | logvar); out[p][c] = (mean + exp(0.5*logvar) * noise[p][c]) * out_scale, noise NULL
+ * = mode.  The reference forms std from the UNCLIPPED logvar (:18); reproduced. */
+int ldm_gaussian_sample(const float* moments, const float* noise, float* out, float out_scale,
+                        int64_t pixels, int C, void* stream);
 
 /* Nearest-codebook lookup (quantize.py:57-78): for each row z of [rows][C] (C <= 8):
  * idx = argmin_e |z|^2+|e|^2-2 z.e over codebook [V][C]; out = z + (e[idx]-z);

@@ -31,7 +31,7 @@ class GemmParams(C.Structure):
       ("OH", c_i32), ("OW", c_i32), ("stride", c_i32), ("upsample", c_i32),
       ("act", c_i32), ("dtype", c_i32), ("out_dtype", c_i32), ("split_k", c_i32),
       ("tile", c_i32), ("alpha", c_f32),
-      ("a_scale", c_vp), ("a_shift", c_vp), ("a_silu", c_i32),
+      ("a_scale", c_vp), ("a_shift", c_vp), ("a_silu", c_i32), ("no_lead_pad", c_i32),
   ]
 
 
@@ -64,6 +64,7 @@ SIGNATURES = {
     "ldm_cfg_ddim_update": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32,
                                     c_f32, c_i32, c_i32, c_i64, c_vp]),
     "ldm_post_quant": (c_i32, [c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ldm_gaussian_sample": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_vp]),
     "ldm_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "ldm_embedding": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ldm_minmax_u8": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_i32, c_i64, c_vp]),

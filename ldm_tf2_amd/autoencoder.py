@@ -1,9 +1,11 @@
-"""First-stage decoders on the HIP path -- host side (decode only).
+"""First-stage autoencoders on the HIP path -- host side.
 
 Mirrors `AutoencoderKL.decode` (autoencoder.py:361-364) and `AutoencoderVQ.decode`
 (:430-436) with the reference constructors' kwargs (= YAML `autoencoder_kl` /
 `autoencoder_vq`).  `decode(latents f32 [B,h,w,4]) -> f32 [B,8h,8w,3]`, NHWC.
-Encoders are out of scope (training / img2latent only).
+`encode` (:353-359 KL, :411-419 VQ) is built when the model is
+constructed with `with_encoder=True` (or handed encoder weights): images f32 [B,H,W,3] ->
+DiagonalGaussian (KL) / (latents, codebook_loss, indices) (VQ).
 
 VQ: the reference binds the quantizer's 3-tuple to `latents` (:432), which cannot
 run; the intended element 0 (the quantised latents) is used.
@@ -14,7 +16,7 @@ import torch
 
 from . import layout as L
 from . import ops
-from .weights import decoder_manifest, init_weights
+from .weights import decoder_manifest, encoder_manifest, init_weights
 
 GROUP_NORM_EPS = 1e-6   # autoencoder.py:11
 
@@ -41,32 +43,8 @@ class _Attn:
     self.c = g("dense_query/kernel").shape[0]
 
 
-class _Decoder:
-  """Decoder (autoencoder.py:252-298) + post_quant_conv (+ VQ codebook)."""
-
-  def __init__(self, weights, dtype, device, attention_resolutions):
-    w, dev = weights, device
-    self.dtype, self.device = dtype, dev
-    self.attention_resolutions = tuple(attention_resolutions)
-    self.codebook = L.vec(w["quantize/kernel"], dev) if "quantize/kernel" in w else None
-    self.post_quant = (L.vec(w["post_quant_conv/kernel"], dev), L.vec(w["post_quant_conv/bias"], dev))
-    self.conv_in = (L.vec(w["decoder/conv_in/kernel"], dev), L.vec(w["decoder/conv_in/bias"], dev))
-    self.mid = (_Res(w, "decoder/middle/residual1", dtype, dev),
-                _Attn(w, "decoder/middle/attention", dtype, dev),
-                _Res(w, "decoder/middle/residual2", dtype, dev))
-    self.up = []
-    i = 0
-    while any(k.startswith(f"decoder/up/{i}/") for k in w):
-      p = f"decoder/up/{i}"
-      if (p + "/conv/kernel") in w:
-        self.up.append(("up", L.conv_kernel(w[p + "/conv/kernel"], dtype, dev), L.vec(w[p + "/conv/bias"], dev)))
-      else:
-        a = _Attn(w, p + "/attention", dtype, dev) if (p + "/attention/group_norm/gamma") in w else None
-        self.up.append(("res", _Res(w, p + "/residual", dtype, dev), a))
-      i += 1
-    self.gn_out = (L.vec(w["decoder/group_norm/gamma"], dev), L.vec(w["decoder/group_norm/beta"], dev))
-    self.conv_out = (L.vec(w["decoder/conv_out/kernel"], dev), L.vec(w["decoder/conv_out/bias"], dev))
-    self.buf = L.Buffers(dev)
+class _Blocks:
+  """ResidualBlock / AttentionBlock launches shared by the decoder and the encoder."""
 
   def _res(self, r, x, out):
     """autoencoder.py:42-58 with time=None."""
@@ -117,6 +95,34 @@ class _Decoder:
       t = self.buf.get("act_b", shape, self.dtype)
     return t
 
+
+class _Decoder(_Blocks):
+  """Decoder (autoencoder.py:252-298) + post_quant_conv (+ VQ codebook)."""
+
+  def __init__(self, weights, dtype, device, attention_resolutions):
+    w, dev = weights, device
+    self.dtype, self.device = dtype, dev
+    self.attention_resolutions = tuple(attention_resolutions)
+    self.codebook = L.vec(w["quantize/kernel"], dev) if "quantize/kernel" in w else None
+    self.post_quant = (L.vec(w["post_quant_conv/kernel"], dev), L.vec(w["post_quant_conv/bias"], dev))
+    self.conv_in = (L.vec(w["decoder/conv_in/kernel"], dev), L.vec(w["decoder/conv_in/bias"], dev))
+    self.mid = (_Res(w, "decoder/middle/residual1", dtype, dev),
+                _Attn(w, "decoder/middle/attention", dtype, dev),
+                _Res(w, "decoder/middle/residual2", dtype, dev))
+    self.up = []
+    i = 0
+    while any(k.startswith(f"decoder/up/{i}/") for k in w):
+      p = f"decoder/up/{i}"
+      if (p + "/conv/kernel") in w:
+        self.up.append(("up", L.conv_kernel(w[p + "/conv/kernel"], dtype, dev), L.vec(w[p + "/conv/bias"], dev)))
+      else:
+        a = _Attn(w, p + "/attention", dtype, dev) if (p + "/attention/group_norm/gamma") in w else None
+        self.up.append(("res", _Res(w, p + "/residual", dtype, dev), a))
+      i += 1
+    self.gn_out = (L.vec(w["decoder/group_norm/gamma"], dev), L.vec(w["decoder/group_norm/beta"], dev))
+    self.conv_out = (L.vec(w["decoder/conv_out/kernel"], dev), L.vec(w["decoder/conv_out/bias"], dev))
+    self.buf = L.Buffers(dev)
+
   def decode(self, latents, scale_factor=1.0, force_quantize=False):
     """latents f32 [B,h,w,C]; computes Decoder(post_quant(quantize?(latents / scale_factor)))."""
     assert latents.dtype == torch.float32 and latents.is_contiguous()
@@ -164,21 +170,116 @@ class _Decoder:
     return out
 
 
+class _Encoder(_Blocks):
+  """Encoder (autoencoder.py:198-249) + quant_conv."""
+
+  def __init__(self, weights, dtype, device, attention_resolutions):
+    w, dev = weights, device
+    self.dtype, self.device = dtype, dev
+    self.attention_resolutions = tuple(attention_resolutions)
+    self.conv_in = (L.vec(w["encoder/conv_in/kernel"], dev), L.vec(w["encoder/conv_in/bias"], dev))
+    self.down = []
+    i = 0
+    while any(k.startswith(f"encoder/down/{i}/") for k in w):
+      p = f"encoder/down/{i}"
+      if (p + "/conv/kernel") in w:
+        self.down.append(("down", L.conv_kernel(w[p + "/conv/kernel"], dtype, dev), L.vec(w[p + "/conv/bias"], dev)))
+      else:
+        a = _Attn(w, p + "/attention", dtype, dev) if (p + "/attention/group_norm/gamma") in w else None
+        self.down.append(("res", _Res(w, p + "/residual", dtype, dev), a))
+      i += 1
+    self.mid = (_Res(w, "encoder/middle/residual1", dtype, dev),
+                _Attn(w, "encoder/middle/attention", dtype, dev),
+                _Res(w, "encoder/middle/residual2", dtype, dev))
+    self.gn_out = (L.vec(w["encoder/group_norm/gamma"], dev), L.vec(w["encoder/group_norm/beta"], dev))
+    self.conv_out = (L.conv_kernel(w["encoder/conv_out/kernel"], dtype, dev), L.vec(w["encoder/conv_out/bias"], dev))
+    self.quant = (L.vec(w["quant_conv/kernel"], dev), L.vec(w["quant_conv/bias"], dev))
+    self.zc = w["quant_conv/kernel"].shape[0]
+    self.buf = L.Buffers(dev)
+
+  def encode(self, images):
+    """images f32 [B,H,W,3] -> quant_conv(Encoder(images)) f32 [B,H/f,W/f,zc]."""
+    assert images.dtype == torch.float32 and images.is_contiguous()
+    B_, dt = self.buf, self.dtype
+    B, H, W, _ = images.shape
+    self._gnp = B_.get("gn_partial", (B * 128 * 32 * 2,), torch.float32)
+    ch = self.conv_in[0].shape[-1]
+    cur = self._dst(None, (B, H, W, ch))
+    ops.conv3x3_small(images, self.conv_in[0], self.conv_in[1], cur)
+    for blk in self.down:
+      hh, ww = cur.shape[1], cur.shape[2]
+      if blk[0] == "down":                                               # autoencoder.py:133-136
+        dst = self._dst(cur, (B, hh // 2, ww // 2, blk[1].shape[0]))
+        cur = ops.conv3x3(cur, blk[1], dst, bias=blk[2], stride=2, no_lead_pad=True)
+      else:
+        _, r, a = blk
+        cur = self._res(r, cur, self._dst(cur, (B, hh, ww, r.cout)))
+        if a is not None and hh in self.attention_resolutions:            # autoencoder.py:117
+          cur = self._attn(a, cur, self._dst(cur, (B, hh, ww, r.cout)))
+    shp = tuple(cur.shape)
+    cur = self._res(self.mid[0], cur, self._dst(cur, shp))
+    cur = self._attn(self.mid[1], cur, self._dst(cur, shp))
+    cur = self._res(self.mid[2], cur, self._dst(cur, shp))
+    t0 = B_.get("gn", shp, dt)
+    ops.groupnorm(cur, self.gn_out[0], self.gn_out[1], t0, GROUP_NORM_EPS, silu=True, partial=self._gnp)
+    h = B_.get("enc_h", (B, shp[1], shp[2], self.zc), torch.float32)
+    ops.conv3x3(t0, self.conv_out[0], h, bias=self.conv_out[1])
+    out = torch.empty(B, shp[1], shp[2], self.zc, dtype=torch.float32, device=self.device)
+    ops.post_quant(h, 1.0, self.quant[0], self.quant[1], out)
+    return out
+
+
+class DiagonalGaussian:
+  """distribution.py:6-51 (the members the encode path uses).  `sample(noise=None, seed=0)`:
+  the reference draws tf.random.normal; here the noise is an explicit input or comes from a
+  seeded torch generator."""
+
+  def __init__(self, moments):
+    self._moments = moments
+    c = moments.shape[-1] // 2
+    self._mean = moments[..., :c]
+    self._logvar = torch.clamp(moments[..., c:], -30.0, 20.0)      # :16 (std uses the unclipped value, :18)
+    self._shape = tuple(moments.shape[:-1]) + (c,)
+
+  def mode(self):
+    out = torch.empty(self._shape, dtype=torch.float32, device=self._moments.device)
+    return ops.gaussian_sample(self._moments, out)
+
+  def sample(self, noise=None, seed=0):
+    dev = self._moments.device
+    if noise is None:
+      g = torch.Generator(device="cpu").manual_seed(int(seed))
+      noise = torch.randn(self._shape, generator=g, dtype=torch.float32)
+    noise = torch.as_tensor(noise, dtype=torch.float32).to(dev).contiguous()
+    out = torch.empty(self._shape, dtype=torch.float32, device=dev)
+    return ops.gaussian_sample(self._moments, out, noise=noise)
+
+
 class _AutoencoderBase:
   _is_vq = False
 
-  def _build(self, man_kwargs, weights, dtype, device, init, seed, attention_resolutions):
+  def _build(self, man_kwargs, weights, dtype, device, init, seed, attention_resolutions,
+             with_encoder=None, enc_kwargs=None):
     self.dtype, self.device = dtype, torch.device(device)
     self.manifest = decoder_manifest(**man_kwargs)
+    if with_encoder is None:
+      with_encoder = weights is not None and "encoder/conv_in/kernel" in weights
+    if with_encoder:
+      self.manifest.update(encoder_manifest(**enc_kwargs))
     if weights is None:
       weights = init_weights(self.manifest, seed=seed, mode=init, scope="autoencoder")
     missing = [k for k in self.manifest if k not in weights]
     if missing:
       raise KeyError(f"autoencoder weights missing {len(missing)} tensors, e.g. {missing[:3]}")
     self._decoder = _Decoder(weights, dtype, self.device, attention_resolutions)
+    self._encoder = _Encoder(weights, dtype, self.device, attention_resolutions) if with_encoder else None
 
-  def encode(self, *a, **k):
-    raise NotImplementedError("encode is outside the sampling path (SURVEY.md section 8f, N4)")
+  def _encode(self, inputs):
+    if self._encoder is None:
+      raise RuntimeError("this autoencoder was built without its encoder: pass with_encoder=True "
+                         "(or weights that contain encoder/*)")
+    x = torch.as_tensor(inputs, dtype=torch.float32).to(self.device).contiguous()
+    return self._encoder.encode(x)
 
 
 class AutoencoderKL(_AutoencoderBase):
@@ -187,14 +288,22 @@ class AutoencoderKL(_AutoencoderBase):
 
   def __init__(self, latent_channels=4, channels=128, num_blocks=2, attention_resolutions=(),
                dropout_rate=0., multipliers=(1, 2, 4, 4), resample_with_conv=True, *,
-               weights=None, dtype=torch.float32, device="cuda:0", init="keras", seed=2):
+               weights=None, dtype=torch.float32, device="cuda:0", init="keras", seed=2,
+               with_encoder=None, image_size=256):
     if not resample_with_conv:
       raise NotImplementedError("resample_with_conv=False is not on the sampling path")
     self._latent_channels, self._channels, self._num_blocks = latent_channels, channels, num_blocks
     self._multipliers = tuple(multipliers)
     self._build(dict(latent_channels=latent_channels, channels=channels, num_blocks=num_blocks,
                      multipliers=self._multipliers, attention_resolutions=()),
-                weights, dtype, device, init, seed, ())
+                weights, dtype, device, init, seed, (), with_encoder,
+                dict(latent_channels=latent_channels, channels=channels, num_blocks=num_blocks,
+                     multipliers=self._multipliers, attention_resolutions=(), image_size=image_size,
+                     double_z=True))
+
+  def encode(self, inputs, training=False):
+    """autoencoder.py:353-359: images [B,H,W,3] -> DiagonalGaussian posterior."""
+    return DiagonalGaussian(self._encode(inputs))
 
   def decode(self, inputs, training=False, scale_factor=1.0):
     """autoencoder.py:361-364."""
@@ -211,7 +320,8 @@ class AutoencoderVQ(_AutoencoderBase):
   def __init__(self, latent_channels=4, channels=128, num_blocks=2, dropout_rate=0,
                multipliers=(1, 2, 2, 4), resample_with_conv=True, attention_resolutions=(32,),
                vocab_size=16384, beta=0.25, *, latent_size=32, weights=None,
-               dtype=torch.float32, device="cuda:0", init="keras", seed=2):
+               dtype=torch.float32, device="cuda:0", init="keras", seed=2, with_encoder=None,
+               image_size=None):
     if not resample_with_conv:
       raise NotImplementedError("resample_with_conv=False is not on the sampling path")
     self._latent_channels, self._channels, self._num_blocks = latent_channels, channels, num_blocks
@@ -220,7 +330,24 @@ class AutoencoderVQ(_AutoencoderBase):
     self._build(dict(latent_channels=latent_channels, channels=channels, num_blocks=num_blocks,
                      multipliers=self._multipliers, attention_resolutions=self._attention_resolutions,
                      latent_size=latent_size, vocab_size=vocab_size),
-                weights, dtype, device, init, seed, self._attention_resolutions)
+                weights, dtype, device, init, seed, self._attention_resolutions, with_encoder,
+                dict(latent_channels=latent_channels, channels=channels, num_blocks=num_blocks,
+                     multipliers=self._multipliers, attention_resolutions=self._attention_resolutions,
+                     image_size=image_size or latent_size * 2 ** (len(self._multipliers) - 1),
+                     double_z=False))
+
+  def encode(self, inputs, only_encode=False, training=False):
+    """autoencoder.py:411-419: latents, or (quantized latents, codebook_loss, indices)."""
+    z = self._encode(inputs)
+    if only_encode:
+      return z
+    q = torch.empty_like(z)
+    idx = torch.empty(z.numel() // z.shape[-1], dtype=torch.int64, device=z.device)
+    ops.vq_nearest(z, self._decoder.codebook, q, indices=idx)
+    # quantize.py:80-85 (forward value; a training-only scalar, formed with torch on the device)
+    e = self._decoder.codebook[idx].reshape(z.shape)
+    loss = ((e - z) ** 2).mean() * (1.0 + self._beta)
+    return q, loss, idx
 
   def decode(self, latents, force_quantize=False, training=False, scale_factor=1.0):
     """autoencoder.py:430-436."""

@@ -183,6 +183,50 @@ def decoder_rules(manifest, num_blocks=2, num_levels=4):
   return {k: v for k, v in r.items() if k in manifest}
 
 
+def encoder_rules(manifest, num_blocks=2, num_levels=4):
+  """convert_ckpt_pytorch_to_tf2.py:306-372 (+ :414-416 for quant_conv)."""
+  E = "first_stage_model.encoder."
+  r = {"quant_conv/kernel": ("first_stage_model.quant_conv.weight", _c1),
+       "quant_conv/bias": ("first_stage_model.quant_conv.bias", _ID),
+       "encoder/conv_in/kernel": (E + "conv_in.weight", _conv), "encoder/conv_in/bias": (E + "conv_in.bias", _ID),
+       "encoder/group_norm/gamma": (E + "norm_out.weight", _ID), "encoder/group_norm/beta": (E + "norm_out.bias", _ID),
+       "encoder/conv_out/kernel": (E + "conv_out.weight", _conv), "encoder/conv_out/bias": (E + "conv_out.bias", _ID)}
+
+  def attn(ours, theirs):
+    r[f"{ours}/group_norm/gamma"] = (f"{theirs}.norm.weight", _ID)
+    r[f"{ours}/group_norm/beta"] = (f"{theirs}.norm.bias", _ID)
+    for o, t in (("dense_query", "q"), ("dense_key", "k"), ("dense_value", "v"), ("dense_output", "proj_out")):
+      r[f"{ours}/{o}/kernel"] = (f"{theirs}.{t}.weight", _c1)
+      r[f"{ours}/{o}/bias"] = (f"{theirs}.{t}.bias", _ID)
+
+  di = 0
+  for lvl in range(num_levels):
+    for j in range(num_blocks):
+      _res_rules(f"encoder/down/{di}/residual", f"{E}down.{lvl}.block.{j}", r, temb=False, ae=True)
+      attn(f"encoder/down/{di}/attention", f"{E}down.{lvl}.attn.{j}")
+      di += 1
+    if lvl < num_levels - 1:
+      r[f"encoder/down/{di}/conv/kernel"] = (f"{E}down.{lvl}.downsample.conv.weight", _conv)
+      r[f"encoder/down/{di}/conv/bias"] = (f"{E}down.{lvl}.downsample.conv.bias", _ID)
+      di += 1
+  _res_rules("encoder/middle/residual1", E + "mid.block_1", r, temb=False, ae=True)
+  attn("encoder/middle/attention", E + "mid.attn_1")
+  _res_rules("encoder/middle/residual2", E + "mid.block_2", r, temb=False, ae=True)
+  return {k: v for k, v in r.items() if k in manifest}
+
+
+def _ae_manifest_rules(cfg, with_encoder, kl=True):
+  cfg = dict(cfg or {})
+  am = Wt.decoder_manifest(**cfg)
+  nb, nl = cfg.get("num_blocks", 2), len(cfg.get("multipliers", (1, 2, 4, 4)))
+  rules = decoder_rules(am, nb, nl)
+  if with_encoder:
+    em = Wt.encoder_manifest(**cfg, double_z=kl)
+    am.update(em)
+    rules.update(encoder_rules(em, nb, nl))
+  return am, rules
+
+
 def _apply(manifest, rules, sd, what):
   missing = [k for k in manifest if k not in rules]
   if missing:
@@ -199,20 +243,22 @@ def _apply(manifest, rules, sd, what):
   return out
 
 
-def from_compvis_state_dict(sd, unet_cfg=None, transformer_cfg=None, autoencoder_cfg=None):
+def from_compvis_state_dict(sd, unet_cfg=None, transformer_cfg=None, autoencoder_cfg=None,
+                            with_encoder=None, kl=True):
   """`sd`: name -> ndarray.  Returns dict(unet=..., cond_stage_model=..., autoencoder=...)
-  of reference-layout float32 weights for the txt2img-f8 configuration (or the given ones)."""
+  of reference-layout float32 weights for the txt2img-f8 configuration (or the given ones).
+  `with_encoder` (default: if the checkpoint has one) adds encoder/* and quant_conv/*."""
   um = Wt.unet_manifest(**(unet_cfg or {}))
   tm = Wt.transformer_manifest(**(transformer_cfg or dict(encoder_stack_size=32, hidden_size=1280, filter_size=5120)))
-  am = Wt.decoder_manifest(**(autoencoder_cfg or {}))
+  if with_encoder is None:
+    with_encoder = "first_stage_model.encoder.conv_in.weight" in sd
+  am, arules = _ae_manifest_rules(autoencoder_cfg, with_encoder, kl)
   heads_u = (unet_cfg or {}).get("num_heads", 8)
   heads_t = (transformer_cfg or {}).get("num_heads", 8)
   return {
       "unet": _apply(um, unet_rules(um, heads_u), sd, "unet"),
       "cond_stage_model": _apply(tm, transformer_rules(tm, heads_t), sd, "cond_stage_model"),
-      "autoencoder": _apply(am, decoder_rules(am, (autoencoder_cfg or {}).get("num_blocks", 2),
-                                              len((autoencoder_cfg or {}).get("multipliers", (1, 2, 4, 4)))), sd,
-                            "autoencoder"),
+      "autoencoder": _apply(am, arules, sd, "autoencoder"),
   }
 
 
@@ -235,16 +281,15 @@ def _inv(fn, a):
   raise TypeError("unknown transform")
 
 
-def to_compvis_state_dict(weights, unet_cfg=None, transformer_cfg=None, autoencoder_cfg=None):
+def to_compvis_state_dict(weights, unet_cfg=None, transformer_cfg=None, autoencoder_cfg=None, kl=True):
   """Inverse of from_compvis_state_dict: reference-layout weights -> CompVis names/layouts."""
   um = Wt.unet_manifest(**(unet_cfg or {}))
   tm = Wt.transformer_manifest(**(transformer_cfg or dict(encoder_stack_size=32, hidden_size=1280, filter_size=5120)))
-  am = Wt.decoder_manifest(**(autoencoder_cfg or {}))
+  am, arules = _ae_manifest_rules(autoencoder_cfg, "encoder/conv_in/kernel" in weights["autoencoder"], kl)
   sd = {}
   for part, m, rules in (("unet", um, unet_rules(um, (unet_cfg or {}).get("num_heads", 8))),
                          ("cond_stage_model", tm, transformer_rules(tm, (transformer_cfg or {}).get("num_heads", 8))),
-                         ("autoencoder", am, decoder_rules(am, (autoencoder_cfg or {}).get("num_blocks", 2),
-                                                           len((autoencoder_cfg or {}).get("multipliers", (1, 2, 4, 4)))))):
+                         ("autoencoder", am, arules)):
     for name in m:
       key, fn = rules[name]
       sd[key] = _inv(fn, weights[part][name])

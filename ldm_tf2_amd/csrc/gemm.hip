@@ -49,7 +49,7 @@ struct GemmArgs {
   uint32_t a_bytes, w_bytes;   // addressable extent from the (per-batch) base pointers
   int M, N, K, batch;
   int add_rows;
-  int conv, H, W, Cin, OH, OW, stride, upsample;
+  int conv, H, W, Cin, OH, OW, stride, upsample, pad;
   int act, out_dtype;
   int split_k, ktiles_per_split, ktiles;
   int tiles_m, tiles_n;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         const int ohw = p.OH * p.OW;
         const int b = m / ohw, rem = m - b * ohw;
         const int oy = rem / p.OW, ox = rem - oy * p.OW;
-        const int iy0 = oy * p.stride - 1, ix0 = ox * p.stride - 1;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
         const int Hs = MODE == 2 ? p.H * 2 : p.H, Ws = MODE == 2 ? p.W * 2 : p.W;
         int mask = 0;
 #pragma unroll
@@ -602,7 +602,9 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     LDM_CHECK_ARG(p->H < 32768 && p->W < 32768, "ldm_gemm(conv): H/W too large");
     LDM_CHECK_ARG(!(p->upsample && p->stride != 1), "ldm_gemm(conv): upsample needs stride 1");
     const int hs = p->upsample ? 2 * p->H : p->H, wsz = p->upsample ? 2 * p->W : p->W;
-    LDM_CHECK_ARG(p->OH == (hs + 2 - 3) / p->stride + 1 && p->OW == (wsz + 2 - 3) / p->stride + 1,
+    LDM_CHECK_ARG(!p->no_lead_pad || (p->stride == 2 && !p->a_scale), "ldm_gemm(conv): no_lead_pad needs stride 2");
+    const int padsum = p->no_lead_pad ? 1 : 2;
+    LDM_CHECK_ARG(p->OH == (hs + padsum - 3) / p->stride + 1 && p->OW == (wsz + padsum - 3) / p->stride + 1,
                   "ldm_gemm(conv): OH/OW inconsistent with H/W/stride/upsample");
     LDM_CHECK_ARG(p->M == p->B * p->OH * p->OW, "ldm_gemm(conv): M != B*OH*OW");
     LDM_CHECK_ARG(p->batch == 1, "ldm_gemm(conv): batch must be 1");
@@ -646,7 +648,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   a.a_bytes = (uint32_t)a_bytes; a.w_bytes = (uint32_t)w_bytes;
   a.add_rows = p->add_rows > 0 ? p->add_rows : 1;
   a.conv = p->conv; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.OH = p->OH; a.OW = p->OW;
-  a.stride = p->stride; a.upsample = p->upsample; a.act = p->act; a.out_dtype = p->out_dtype;
+  a.stride = p->stride; a.upsample = p->upsample; a.pad = p->no_lead_pad ? 0 : 1; a.act = p->act; a.out_dtype = p->out_dtype;
   a.alpha = p->alpha;
   // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
   const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;

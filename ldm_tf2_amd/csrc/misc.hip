@@ -223,6 +223,21 @@ __global__ __launch_bounds__(256) void post_quant_kernel(const float* __restrict
   }
 }
 
+// ---- DiagonalGaussian sample / mode ------------------------------------------------------
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __restrict__ mom,
+                                                              const float* __restrict__ noise,
+                                                              float* __restrict__ out, float scale,
+                                                              int64_t total, int C) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t p = i / C;
+    const int c = (int)(i - p * C);
+    const float mean = mom[p * 2 * C + c];
+    float v = mean;
+    if (noise) v = mean + expf(0.5f * mom[p * 2 * C + C + c]) * noise[i];
+    out[i] = v * scale;
+  }
+}
+
 // ---- VQ nearest: one wave per row, lanes stride the codebook ------------------------
 __global__ __launch_bounds__(256) void vq_nearest_kernel(const float* __restrict__ z,
                                                          const float* __restrict__ cb,
@@ -457,6 +472,15 @@ extern "C" int ldm_post_quant(const float* latents, float scale_factor, const fl
     hipLaunchKernelGGL(post_quant_kernel<float>, g, dim3(256), 0, s, latents, scale_factor, kernel_io,
                        bias, (float*)out, pixels, C);
   return ldm_launch_status("ldm_post_quant");
+}
+
+extern "C" int ldm_gaussian_sample(const float* moments, const float* noise, float* out,
+                                   float out_scale, int64_t pixels, int C, void* stream) {
+  LDM_CHECK_ARG(moments && out && pixels > 0 && C > 0, "ldm_gaussian_sample: bad args");
+  dim3 g(grid_for(pixels * C, 256, 4096));
+  hipLaunchKernelGGL(gaussian_sample_kernel, g, dim3(256), 0, (hipStream_t)stream, moments, noise, out,
+                     out_scale, pixels * C, C);
+  return ldm_launch_status("ldm_gaussian_sample");
 }
 
 extern "C" int ldm_vq_nearest(const float* z, const float* codebook, float* out, int64_t* indices,

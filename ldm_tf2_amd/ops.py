@@ -131,11 +131,12 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
 
 
 def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale, a_shift,
-                 a_silu):
+                 a_silu, no_lead_pad=False):
   B, H, W, Cin = x.shape
   Cout = wt.shape[0]
   hs, ws_ = (2 * H, 2 * W) if upsample else (H, W)
-  OH, OW = (hs + 2 - 3) // stride + 1, (ws_ + 2 - 3) // stride + 1
+  pads = 1 if no_lead_pad else 2
+  OH, OW = (hs + pads - 3) // stride + 1, (ws_ + pads - 3) // stride + 1
   assert wt.shape[1] == 9 * Cin and wt.is_contiguous() and wt.dtype == x.dtype
   assert tuple(out.shape) == (B, OH, OW, Cout), (tuple(out.shape), (B, OH, OW, Cout))
   p = GemmParams()
@@ -152,7 +153,7 @@ def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, spl
     p.add_rows = OH * OW
     p.add_ld = addend.stride(0) if (addend.dim() == 2 and addend.shape[0] > 1) else 0
   p.conv, p.B, p.H, p.W, p.Cin, p.OH, p.OW = 1, B, H, W, Cin, OH, OW
-  p.stride, p.upsample = stride, int(bool(upsample))
+  p.stride, p.upsample, p.no_lead_pad = stride, int(bool(upsample)), int(bool(no_lead_pad))
   p.act, p.dtype, p.out_dtype, p.alpha = ACT_NONE, code(x.dtype), code(out.dtype), 1.0
   p.tile, p.split_k = tile, split_k
   if a_scale is not None:
@@ -164,13 +165,14 @@ def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, spl
 
 
 def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residual=None,
-            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False):
+            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False, no_lead_pad=False):
   """3x3 convolution, NHWC, pad 1 (Keras SAME for stride 1; the U-Net's explicit
-  pad(1,1)+VALID for stride 2), optional fused nearest-2x upsample of the input and optional
+  pad(1,1)+VALID for stride 2; `no_lead_pad`: the autoencoder's pad (0,1),(0,1)+VALID stride-2
+  downsample, autoencoder.py:133), optional fused nearest-2x upsample of the input and optional
   GroupNorm(+SiLU) prologue on the input (a_scale/a_shift [B,Cin] from groupnorm_scale_shift).
   x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout]."""
   p = _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale,
-                   a_shift, a_silu)
+                   a_shift, a_silu, no_lead_pad)
   _gemm(p, x.device)
   return out
 
@@ -323,6 +325,16 @@ def post_quant(latents, scale_factor, kernel_io, bias, out):
   check(lib.ldm_post_quant(_ptr(_f32(latents, "latents")), float(scale_factor),
                            _ptr(_f32(kernel_io, "kernel")), _ptr(_f32(bias, "bias")), _ptr(out),
                            code(out.dtype), latents.numel() // Cc, Cc, _stream()), "ldm_post_quant")
+  return out
+
+
+def gaussian_sample(moments, out, noise=None, out_scale=1.0):
+  Cc = out.shape[-1]
+  assert moments.shape[-1] == 2 * Cc and moments.is_contiguous() and out.is_contiguous()
+  assert noise is None or (noise.is_contiguous() and noise.numel() == out.numel())
+  check(lib.ldm_gaussian_sample(_ptr(_f32(moments, "moments")), _ptr(_f32(noise, "noise")),
+                                _ptr(_f32(out, "out")), float(out_scale), out.numel() // Cc, Cc,
+                                _stream()), "ldm_gaussian_sample")
   return out
 
 

@@ -235,6 +235,46 @@ def decoder_manifest(latent_channels=4, channels=128, num_blocks=2,
   return m
 
 
+def encoder_manifest(latent_channels=4, channels=128, num_blocks=2,
+                     multipliers=(1, 2, 4, 4), attention_resolutions=(),
+                     image_size=256, in_channels=3, double_z=True, **_unused):
+  """Variables on the encode path: Encoder
+  (autoencoder.py:198-249) + quant_conv (:330 KL, :406 VQ).  KL: the encoder emits
+  2*latent_channels moments (`double_z`, autoencoder.py:322) and never owns attention in
+  its DownBlocks (:325); VQ: latent_channels and attention where the run-time size is in
+  `attention_resolutions` (autoencoder.py:117), hence `image_size`."""
+  m = OrderedDict()
+  zc = latent_channels * (2 if double_z else 1)
+  cl = [channels * mul for mul in multipliers]
+  m["encoder/conv_in/kernel"] = ((3, 3, in_channels, channels), "kernel")
+  m["encoder/conv_in/bias"] = ((channels,), "bias")
+  ch, size, di = channels, image_size, 0
+  for i in range(len(multipliers)):
+    for _ in range(num_blocks):
+      p = f"encoder/down/{di}"
+      _ae_resblock(m, p + "/residual", ch, cl[i])
+      ch = cl[i]
+      if size in tuple(attention_resolutions):
+        _ae_attention(m, p + "/attention", ch)
+      di += 1
+    if i < len(multipliers) - 1:
+      p = f"encoder/down/{di}"
+      m[p + "/conv/kernel"] = ((3, 3, ch, ch), "kernel")
+      m[p + "/conv/bias"] = ((ch,), "bias")
+      size //= 2
+      di += 1
+  _ae_resblock(m, "encoder/middle/residual1", ch, ch)
+  _ae_attention(m, "encoder/middle/attention", ch)
+  _ae_resblock(m, "encoder/middle/residual2", ch, ch)
+  m["encoder/group_norm/gamma"] = ((ch,), "gamma")
+  m["encoder/group_norm/beta"] = ((ch,), "beta")
+  m["encoder/conv_out/kernel"] = ((3, 3, ch, zc), "kernel")
+  m["encoder/conv_out/bias"] = ((zc,), "bias")
+  m["quant_conv/kernel"] = ((zc, zc), "kernel")
+  m["quant_conv/bias"] = ((zc,), "bias")
+  return m
+
+
 def count_params(manifest):
   return int(sum(int(np.prod(s)) for s, _ in manifest.values()))
 

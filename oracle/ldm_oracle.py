@@ -346,6 +346,52 @@ def decoder_forward(latents, weights, dtype=torch.float32, attention_resolutions
   return conv2d(h, d("conv_out/kernel"), d("conv_out/bias"))
 
 
+def encoder_forward(images, weights, dtype=torch.float32, attention_resolutions=()):
+  """Encoder.call (autoencoder.py:240-249) followed by quant_conv (:356 KL, :413 VQ).
+  DownBlock = ResidualBlock (+ AttentionBlock when the run-time height is in
+  `attention_resolutions`, :117); Downsample pads [[0,1],[0,1]] then 3x3 stride-2 VALID
+  (:133-136).  images [B,H,W,3] -> [B,H/f,W/f,zc] (KL: zc = 2*latent moments)."""
+  w = W(weights, dtype)
+  e = w.sub("encoder")
+  h = conv2d(_t(images, dtype), e("conv_in/kernel"), e("conv_in/bias"))
+  i = 0
+  while e.has_prefix(f"down/{i}/"):
+    u = e.sub(f"down/{i}")
+    if u.has("conv/kernel"):
+      h = conv2d(h, u("conv/kernel"), u("conv/bias"), stride=2, pad=((0, 1), (0, 1)))
+    else:
+      h = ae_residual_block(h, u.sub("residual"))
+      if h.shape[1] in tuple(attention_resolutions):
+        h = ae_attention_block(h, u.sub("attention"))
+    i += 1
+  h = ae_residual_block(h, e.sub("middle/residual1"))
+  h = ae_attention_block(h, e.sub("middle/attention"))
+  h = ae_residual_block(h, e.sub("middle/residual2"))
+  h = conv2d(silu(group_norm(h, e("group_norm/gamma"), e("group_norm/beta"), eps=AE_GN_EPS)),
+             e("conv_out/kernel"), e("conv_out/bias"))
+  return dense(h, w("quant_conv/kernel"), w("quant_conv/bias"))
+
+
+def diagonal_gaussian(moments, noise=None):
+  """distribution.py:6-25,50-51: mean, logvar = split(moments); the stored logvar is clipped
+  to [-30, 20] but std = exp(0.5 * logvar) uses the UNCLIPPED value (:16-18, reproduced).
+  Returns (mean, clipped logvar, sample) with sample = mean + std * noise (mode if None)."""
+  mean, logvar = torch.chunk(moments, 2, dim=-1)
+  std = torch.exp(0.5 * logvar)
+  sample = mean if noise is None else mean + std * _t(noise, moments.dtype)
+  return mean, torch.clamp(logvar, -30.0, 20.0), sample
+
+
+def vq_encode(images, weights, dtype=torch.float32, attention_resolutions=(), beta=0.25):
+  """AutoencoderVQ.encode (autoencoder.py:411-419): encoder + quant_conv, then the
+  quantizer's (quantized, codebook_loss, indices) (quantize.py:57-90)."""
+  z = encoder_forward(images, weights, dtype, attention_resolutions)
+  q, idx = vq_nearest(z, W(weights, dtype)("quantize/kernel"))
+  qq = W(weights, dtype)("quantize/kernel")[idx].reshape(z.shape)
+  loss = ((qq - z) ** 2).mean() + beta * ((qq - z) ** 2).mean()
+  return z, q, loss, idx
+
+
 # ----------------------------------------------------------------------------
 # model_runners.py : schedule, DDIM step, loop
 # ----------------------------------------------------------------------------
