@@ -111,6 +111,9 @@ typedef struct {
 } ldm_gemm_params;
 
 int ldm_gemm(const ldm_gemm_params* p, void* stream);
+/* the tile configuration and split-K factor ldm_gemm would pick for these params (host only;
+ * nothing is launched) -- for tools and tests of the cost model */
+int ldm_gemm_plan(const ldm_gemm_params* p, int* tile, int* split_k);
 /* bytes of workspace ldm_gemm may need for these params with split_k = 0 (auto) */
 size_t ldm_gemm_workspace_bytes(const ldm_gemm_params* p);
 

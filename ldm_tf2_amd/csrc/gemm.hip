@@ -108,15 +108,20 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   constexpr int NT = NW * 64;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int LA = BM / (8 * NW), LB = BN / (8 * NW);   // LDS-DMA instructions per wave per tile
+  constexpr int BNP = (BN + 8 * NW - 1) / (8 * NW) * (8 * NW);   // B rows staged (>= BN: whole LDS-DMA rounds)
+  constexpr int LA = BM / (8 * NW), LB = BNP / (8 * NW);  // LDS-DMA instructions per wave per tile
   constexpr int NL = LA + LB;
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
   constexpr int BKE = 8 * EPC;
   constexpr int NSTAGE = 2;
-  constexpr int STAGE = (BM + BN) * 128;
-  constexpr int SMEM = NSTAGE * STAGE > BM * BN * 4 ? NSTAGE * STAGE : BM * BN * 4;
-  static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1, "tile");
+  constexpr int STAGE = (BM + BNP) * 128;
+  // the 160/320-column tiles stage their f32 epilogue tile in two row passes (LDS budget)
+  constexpr int ESPLIT = (BN % 160 == 0) ? 2 : 1;
+  constexpr int EROWS = BM / ESPLIT;
+  constexpr int SMEM = NSTAGE * STAGE > EROWS * BN * 4 ? NSTAGE * STAGE : EROWS * BN * 4;
+  static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1 && BM % (8 * NW) == 0, "tile");
+  static_assert(EROWS % WTM == 0, "epilogue row pass must hold whole wave tiles");
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   __shared__ __attribute__((aligned(16))) char smem[SMEM];
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int ck = (lane & 7) ^ ((row >> 1) & 7);
     const int n = n0 + row;
-    b_base[i] = n < p.N ? (int)((int64_t)n * p.K * ES) + ck * 16 : (int)kOOB;
+    b_base[i] = (n < p.N && row < BN) ? (int)((int64_t)n * p.K * ES) + ck * 16 : (int)kOOB;
   }
   const int row_pitch = (int)(p.lda * ES);          // bytes per pixel
   const int line_pitch = p.W * row_pitch;           // bytes per image line
@@ -321,25 +326,30 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     // (1) accumulators -> f32 tile [BM][BN] in LDS (the staging buffers are dead: the
     //     K loop's last barrier has been passed by every wave)
     float* sC = (float*)smem;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          sC[row * BN + wn * WTN + j * 32 + lr] = acc[i][j][r] * p.alpha;
-        }
-    __syncthreads();
-    // (2) row-wise pieces of 8 output columns per thread
     const bool geglu = p.act == LDM_ACT_GEGLU;
     constexpr int PCOLS = BN / 8;                 // pieces per tile row (plain)
     const int pcols = geglu ? PCOLS / 2 : PCOLS;
-    const int npieces = BM * pcols;
+    const int npieces = EROWS * pcols;
     const int nout = geglu ? p.N / 2 : p.N;
+#pragma unroll
+   for (int ep = 0; ep < ESPLIT; ++ep) {
+    if (ep > 0) __syncthreads();                  // previous pass fully read
+    if ((wm * WTM) / EROWS == ep) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM - ep * EROWS + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            sC[row * BN + wn * WTN + j * 32 + lr] = acc[i][j][r] * p.alpha;
+          }
+    }
+    __syncthreads();
+    // (2) row-wise pieces of 8 output columns per thread
     for (int c = tid; c < npieces; c += NT) {
       const int row = c / pcols, pc = c - row * pcols;
-      const int m = m0 + row;
+      const int m = m0 + ep * EROWS + row;
       int ncol, lcol;                             // first output column, first LDS column (value)
       if (geglu) {
         const int oc = pc * 8;                    // within the tile's BN/2 output columns
@@ -408,6 +418,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         *(f32x4*)((float*)p.out + ooff + 4) = o1;
       }
     }
+   }
     return;
   }
 
@@ -507,8 +518,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
 
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
-constexpr TileCfg kTiles[6] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {256, 128}};
-constexpr int kResident[6] = {0, 1, 2, 3, 5, 1};   // workgroups per CU (LDS-limited: 2-stage ring)
+constexpr int kNumTiles = 9;
+constexpr TileCfg kTiles[kNumTiles] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {256, 128},
+                                       {128, 160}, {256, 160}, {128, 320}};   // 6-8: N = 320*k layers
+constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1};   // workgroups per CU (LDS-limited: 2-stage ring)
 
 template <typename T, int MODE>
 void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
@@ -517,6 +530,9 @@ void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
     case 2: hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
     case 3: hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
     case 5: hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;   // 4 waves x (128x64)
+    case 6: hipLaunchKernelGGL((gemm_kernel<T, 128, 160, 4, 1, MODE>), grid, dim3(256), 0, s, a); break;   // 4 waves x (32x160)
+    case 7: hipLaunchKernelGGL((gemm_kernel<T, 256, 160, 8, 1, MODE>), grid, dim3(512), 0, s, a); break;   // 8 waves x (32x160)
+    case 8: hipLaunchKernelGGL((gemm_kernel<T, 128, 320, 4, 2, MODE>), grid, dim3(512), 0, s, a); break;   // 8 waves x (32x160)
     default: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
   }
 }
@@ -535,18 +551,20 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // measured time one CU needs for one K-tile of that configuration with its resident
 // workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
-  static const double kStepUs[6] = {0, 0.82, 0.82, 0.75, 0.87, 0.82};     // bf16, per round per K-tile (resident WGs co-running)
-  static const double kOverheadSteps[6] = {0, 8, 8, 7, 6, 8};          // launch + prologue + epilogue, in K-tiles
+  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15};   // bf16, per round per K-tile (resident WGs co-running)
+  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8};   // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
+  static const bool no160 = getenv("LDM_GEMM_NO160") != nullptr;   // A/B switch for tools/
   const int bke = 128 / esize;
   const int ktiles = cdiv(p->K, bke);
   const bool geglu = p->act == LDM_ACT_GEGLU;
   const double f32x = esize == 4 ? 8.0 : 1.0;   // f32 MFMA: 1/16 the rate at half the K per tile
   double best = 1e30;
   int best_cfg = 2, best_split = 1;
-  for (int c = 1; c <= 5; ++c) {
-    if (p->tile > 0 && p->tile <= 5 && c != p->tile) continue;
+  for (int c = 1; c < kNumTiles; ++c) {
+    if (p->tile > 0 && p->tile < kNumTiles && c != p->tile) continue;
     if (c == 5 && p->tile != 5) continue;   // experimental: only when forced
+    if (c >= 6 && p->tile != c && (p->N % kTiles[c].bn != 0 || no160)) continue;   // 160/320-column tiles: N = 160*k layers
     if (geglu && c > 2 && c != 5) continue;
     const TileCfg t = kTiles[c];
     const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
@@ -565,7 +583,7 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
     }
   }
   if (p->split_k > 0 && p->batch == 1) best_split = p->split_k;
-  if (p->tile > 0 && p->tile <= 5) best_cfg = p->tile;
+  if (p->tile > 0 && p->tile < kNumTiles) best_cfg = p->tile;
   *cfg_out = best_cfg;
   *split_out = best_split;
 }
@@ -577,6 +595,13 @@ extern "C" size_t ldm_gemm_workspace_bytes(const ldm_gemm_params* p) {
   int cfg, split;
   choose(p, p->dtype == LDM_BF16 ? 2 : 4, &cfg, &split);
   return split > 1 ? (size_t)split * p->M * p->N * 4 : 0;
+}
+
+extern "C" int ldm_gemm_plan(const ldm_gemm_params* p, int* tile, int* split_k) {
+  LDM_CHECK_ARG(p && tile && split_k, "ldm_gemm_plan: null pointer");
+  LDM_CHECK_ARG(p->dtype == LDM_F32 || p->dtype == LDM_BF16, "ldm_gemm_plan: bad dtype %d", p->dtype);
+  choose(p, p->dtype == LDM_BF16 ? 2 : 4, tile, split_k);
+  return LDM_OK;
 }
 
 extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {

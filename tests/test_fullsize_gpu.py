@@ -8,7 +8,7 @@
     per-sample), a run is reproducible, and sharding a batch over ranks (different
     first_sample_index) reproduces the unsharded run sample for sample -- the property the
     multi-GPU path relies on.
-Tolerances as in tests/test_models_gpu.py (relative L2): f32 2e-4, bf16 4e-2.
+Tolerances as in tests/test_models_gpu.py (relative L2): f32 5e-5, bf16 4e-2.
 """
 import numpy as np
 import pytest
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 from ldm_tf2_amd import weights as Wt  # noqa: E402
 from oracle import ldm_oracle as O  # noqa: E402
 
-REL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+REL = {torch.float32: 5e-5, torch.bfloat16: 4e-2}
 UNET = dict(model_channels=320, out_channels=4, num_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8)
 TXT = dict(vocab_size=30522, encoder_stack_size=32, hidden_size=1280, num_heads=8, size_per_head=64,
            max_seq_len=77, filter_size=5120)
@@ -132,7 +132,7 @@ def test_fullsize_loop_properties(dev, unet_w, kl_w):
   # identical x_T and per-sample arithmetic; only tile shapes (hence summation order) may differ
   r = rel(halves, full.cpu())
   print(f"sharded vs unsharded [{dt}] rel={r:.3e}")
-  assert r < 2e-4
+  assert r < 5e-5
   # 512x512 (latent 64x64, BASELINE configs[4]) runs and is finite
   big = s.ddim_p_sample_loop(ids(1), [1, 64, 64, 4], 5., seed=0)
   assert tuple(big.shape) == (1, 512, 512, 3) and bool(torch.isfinite(big).all())

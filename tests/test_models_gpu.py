@@ -4,7 +4,11 @@ seconds.  Same seeded weights (ldm_tf2_amd.weights.init_weights, mode="random" s
 that biases and affine parameters are exercised), same x_T, same token ids.
 
 Tolerances (relative L2 error ||got-ref|| / ||ref||, and max-abs):
-  float32 : 2e-4 rel  -- summation order only (the f32 MFMA is an exact fma chain)
+  float32 : 5e-5 rel  -- summation order only (the f32 MFMA is an exact fma chain).  Calibrated
+            (tools/calibrate_tolerance.py, profiles/r01_tolerance_calibration.txt): the oracle's
+            own float32-vs-float64 drift is 2e-6 .. 4e-6 for one U-Net evaluation (tiny and
+            full-size), a decoder pass and the free-running 10/50-step loops; the gate is ~12x
+            that noise floor, and the HIP path measures 2e-6 .. 7e-6.
   bfloat16: 4e-2 rel  -- bf16 storage of weights and activations, f32 accumulation
 """
 import numpy as np
@@ -16,7 +20,7 @@ pytestmark = pytest.mark.gpu
 from ldm_tf2_amd import weights as Wt  # noqa: E402
 from oracle import ldm_oracle as O  # noqa: E402
 
-REL = {torch.float32: 2e-4, torch.bfloat16: 4e-2}
+REL = {torch.float32: 5e-5, torch.bfloat16: 4e-2}
 DT = [torch.float32, torch.bfloat16]
 
 UNET_CFG = dict(model_channels=64, out_channels=4, num_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8)

@@ -36,8 +36,8 @@ def close(got, ref, dtype, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (64, 192, 1280), (1024, 64, 64)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8])
+@pytest.mark.parametrize("M,N,K", [(300, 320, 320), (64, 192, 1280), (1024, 64, 64), (700, 640, 128)])
 def test_linear(dev, dtype, tile, M, N, K):
   x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
   bias = rnd((N,), torch.float32, 3)
@@ -106,7 +106,7 @@ def test_conv3x3(dev, dtype, cfg):
   res = rnd((B, OH, OW, Cout), dtype, 6)
   ref = ref + res.float()
   wt = k.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous().to(dev)
-  for tile in (0, 1, 2, 3, 4, 11, 12, 13):     # 1-4 implicit GEMM tiles, 11-13 halo tiles
+  for tile in (0, 1, 2, 3, 4, 6, 7, 8, 11, 12, 13):     # 1-8 implicit GEMM tiles, 11-13 halo tiles
     out = torch.zeros(B, OH, OW, Cout, dtype=dtype, device=dev)
     o.conv3x3(x.to(dev), wt, out, bias=bias.to(dev), stride=cfg["stride"], upsample=cfg["up"],
               addend=addend.to(dev), residual=res.to(dev), tile=tile)
