@@ -73,7 +73,11 @@ int ldm_last_error(char* buf, int n);
  * Output element (m, n) of batch b is stored at out + b*stride_c + m*ldc_m + n*ldc_n
  * (ldc_n = 1 for row-major; ldc_m = 1 gives the transposed store used for V^T).
  * With LDM_ACT_GEGLU the stored width is N/2.
- * split_k > 1 needs `workspace` >= split_k*M*N*4 bytes (batch must be 1).
+ * split_k > 1 needs `workspace` >= split_k*M*N*4 bytes (batch must be 1); the f32 partial
+ * slabs are reduced (+ epilogue) by a second small launch.  (An in-kernel "last block
+ * reduces" fix-up was measured and rejected: on this multi-XCD part the agent-scope fence /
+ * device-coherent accesses it needs cost far more than the launch it saves; DESIGN.md.)
+ * One workspace serves one stream at a time.
  */
 typedef struct {
   const void* a;
@@ -142,6 +146,14 @@ int ldm_groupnorm_partial(const void* x, int64_t ldx, float* partial, int B, int
 int ldm_groupnorm_apply(const void* x, int64_t ldx, const float* partial, const float* gamma,
                         const float* beta, void* out, int64_t ldo, int B, int HW, int C,
                         int groups, int nchunks, float eps, int silu, int dtype, void* stream);
+/* Single-launch variant for small images (every U-Net GroupNorm): one workgroup owns whole
+ * groups of one sample and keeps its slab in registers between the passes, so x is read once
+ * and written once, and the variance is the two-pass (centred) form.  _supported is a pure
+ * host query; ldm_groupnorm_fused fails (LDM_ERR_ARG) on an unsupported shape. */
+int ldm_groupnorm_fused_supported(int B, int HW, int C, int groups, int dtype);
+int ldm_groupnorm_fused(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out,
+                        int64_t ldo, int B, int HW, int C, int groups, float eps, int silu, int dtype,
+                        void* stream);
 /* Instead of ldm_groupnorm_apply: fold the statistics into per-(sample, channel)
  * scale = rstd*gamma and shift = beta - mean*scale (float32 [B][C]) for a consumer that
  * normalises on the fly (ldm_gemm's a_scale / a_shift conv prologue). */

@@ -64,6 +64,9 @@ SIGNATURES = {
     "ldm_cfg_ddim_update": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32,
                                     c_f32, c_i32, c_i32, c_i64, c_vp]),
     "ldm_post_quant": (c_i32, [c_vp, c_f32, c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "ldm_groupnorm_fused_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "ldm_groupnorm_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32,
+                                    c_i32, c_i32, c_vp]),
     "ldm_gemm_plan": (c_i32, [c_vp, c_vp, c_vp]),
     "ldm_gaussian_sample": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_vp]),
     "ldm_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),

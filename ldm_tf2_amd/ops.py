@@ -8,6 +8,7 @@ in this module computes with torch ops.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -219,10 +220,23 @@ def conv3x3_small(x, kernel_hwio, bias, out):
   return out
 
 
-def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None):
-  """x, out [B, H, W, C] (channel slices allowed)."""
+_GN_FUSED = os.environ.get("LDM_GN_NO_FUSED") is None
+
+
+def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None, fused=None):
+  """x, out [B, H, W, C] (channel slices allowed).  Small images take the single-launch
+  kernel (`fused`; default: whenever the library supports the shape), large ones the
+  partial-sums + apply pair."""
   B, C = x.shape[0], x.shape[-1]
   HW = x.numel() // (B * C)
+  if fused is None:
+    fused = _GN_FUSED
+  if fused and lib.ldm_groupnorm_fused_supported(B, HW, C, groups, code(x.dtype)):
+    assert out.dtype == x.dtype
+    check(lib.ldm_groupnorm_fused(_ptr(x), row_ld(x), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
+                                  _ptr(out), row_ld(out), B, HW, C, groups, float(eps), int(bool(silu)),
+                                  code(x.dtype), _stream()), "ldm_groupnorm_fused")
+    return out
   nch = lib.ldm_groupnorm_nchunks(B, HW, C)
   if partial is None:
     partial = torch.empty(B * nch * groups * 2, dtype=torch.float32, device=x.device)

@@ -207,6 +207,37 @@ def test_groupnorm(dev, dtype, shape, silu):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(3, 32, 32, 320), (9, 16, 16, 640), (2, 8, 8, 1280), (5, 4, 4, 1280),
+                                   (2, 8, 8, 2560), (2, 16, 16, 1920), (1, 32, 32, 960), (2, 32, 32, 640),
+                                   (2, 64, 64, 320), (2, 5, 7, 320)])
+def test_groupnorm_single_launch(dev, dtype, shape):
+  """The register-resident single-launch kernel (every U-Net GroupNorm shape) against the
+  oracle, against the two-launch path, and run-to-run identical (fixed-order reductions)."""
+  o = ops()
+  from ldm_tf2_amd._lib import lib
+  B, H, W, Cc = shape
+  x = rnd(shape, dtype, 1) * 2 + 0.5
+  gamma, beta = rnd((Cc,), torch.float32, 2) * 0.2 + 1, rnd((Cc,), torch.float32, 3) * 0.2
+  wide = torch.zeros(B, H, W, Cc + 64, dtype=dtype, device=dev)
+  xs = wide[..., 64:]
+  xs.copy_(x)
+  sup = lib.ldm_groupnorm_fused_supported(B, H * W, Cc, 32, o.code(dtype))
+  if shape != (2, 64, 64, 320):     # 4096 pixels x 5 chunks is beyond the register slab: two launches
+    assert sup == 1, shape
+  ref = O.silu(O.group_norm(x.float(), gamma, beta, eps=1e-6))
+  outs = []
+  for fused in (True, True, False):
+    out = torch.full(shape, float("nan"), dtype=dtype, device=dev)
+    o.groupnorm(xs, gamma.to(dev), beta.to(dev), out, eps=1e-6, silu=True, fused=fused)
+    torch.cuda.synchronize()
+    close(out, ref, dtype, scale=2.0)
+    outs.append(out)
+  assert torch.equal(outs[0], outs[1])
+  if dtype == torch.float32:
+    assert (outs[0] - outs[2]).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Cc", [64, 320, 1280])
 def test_layernorm(dev, dtype, Cc):
   o = ops()
