@@ -18,9 +18,10 @@
 //     -- the hardware range check then writes zeros, so the conv's zero padding
 //     costs one v_cndmask per piece and no divergent control flow.  An LDS-DMA
 //     wave-instruction writes 64 x 16 B linearly, so the XOR swizzle is applied
-//     to the SOURCE chunk each lane fetches.  Three LDS stages form a ring: tile
-//     t+2 is issued while tile t is multiplied; a counted s_waitcnt vmcnt(N)
-//     (never 0 in the loop) plus ONE raw s_barrier per K-tile orders it.
+//     to the SOURCE chunk each lane fetches.  Two LDS stages form a ring: tile
+//     t+1 is issued while tile t is multiplied; s_waitcnt vmcnt(0) plus ONE raw
+//     s_barrier per K-tile orders it.  (A 3-stage ring with counted vmcnt was
+//     measured slower: one more stage costs a resident workgroup per CU.)
 //   * the epilogue goes through LDS: accumulators are dropped as an f32 tile and
 //     re-read row-wise so that bias / addend / residual / output all move as
 //     16-byte vectors (the MFMA accumulator layout alone would give 2-byte
@@ -114,8 +115,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
   constexpr int BKE = 8 * EPC;
-  constexpr int NSTAGE = 2;
   constexpr int STAGE = (BM + BNP) * 128;
+  // A third stage (prefetch distance 2) only where it is free: tiles whose two stages already
+  // leave room for just one workgroup per CU (160 KB LDS) and whose three stages still fit.
+  constexpr int kLds = 160 * 1024;
+  constexpr int NSTAGE = (4 * STAGE > kLds && 3 * STAGE <= kLds && WM * WN == 8) ? 3 : 2;
   // the 160/320-column tiles stage their f32 epilogue tile in two row passes (LDS budget)
   constexpr int ESPLIT = (BN % 160 == 0) ? 2 : 1;
   constexpr int EROWS = BM / ESPLIT;
@@ -276,13 +280,23 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // 2-stage ring, prefetch distance 1: at the top of K-tile t every outstanding LDS-DMA
   // belongs to tile t; after the wait + ONE barrier, tile t is visible to all waves and all
   // waves have finished reading the other stage (tile t-1), which tile t+1 may now overwrite.
+  // 3-stage ring (NSTAGE == 3), prefetch distance 2: tiles t and t+1 are outstanding at the
+  // top of K-tile t, so the wait is the counted vmcnt(NL) -- tile t+1's NL LDS-DMAs may still
+  // be in flight -- and tile t+2 goes to the stage tile t-1 was read from.
   if (nk > 0) issue_tile(kt_begin, 0);
+  if (NSTAGE == 3 && nk > 1) issue_tile(kt_begin + 1, 1);
+  int st = 0;
   for (int t = 0; t < nk; ++t) {
-    const int st = t & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NSTAGE == 3 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (t + 1 < nk) issue_tile(kt_begin + t + 1, st ^ 1);
+    if (t + NSTAGE - 1 < nk) {
+      int sn = st + NSTAGE - 1;
+      sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+      issue_tile(kt_begin + t + NSTAGE - 1, sn);
+    }
     const char* cS = smem + st * STAGE;
+    st = st + 1 == NSTAGE ? 0 : st + 1;
     u32x4 fa[4][TM], fb[4][TN];
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
@@ -516,6 +530,92 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(GemmArgs p) {
   }
 }
 
+// sum of the split slabs for 8 consecutive logical columns of row m, in split order
+__device__ __forceinline__ void splitk_sum8(const GemmArgs& p, int m, int nlog, float (&v)[8]) {
+  const float* src = p.ws + (int64_t)m * p.N + nlog;
+  const int64_t slab = (int64_t)p.M * p.N;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  int s = 0;
+  for (; s + 4 <= p.split_k; s += 4) {          // 8 x 16-byte loads in flight, then ordered adds
+    f32x4 t[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      t[u][0] = *(const f32x4*)(src + (s + u) * slab);
+      t[u][1] = *(const f32x4*)(src + (s + u) * slab + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { v[e] += t[u][0][e]; v[4 + e] += t[u][1][e]; }
+  }
+  for (; s < p.split_k; ++s) {
+    const f32x4 t0 = *(const f32x4*)(src + s * slab), t1 = *(const f32x4*)(src + s * slab + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += t0[e]; v[4 + e] += t1[e]; }
+  }
+  if (p.bias) {
+    const f32x4 b0 = *(const f32x4*)(p.bias + nlog), b1 = *(const f32x4*)(p.bias + nlog + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = v[e] * p.alpha + b0[e]; v[4 + e] = v[4 + e] * p.alpha + b1[e]; }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
+  }
+  if (p.addend) {
+    const float* ad = p.addend + (int64_t)(m / p.add_rows) * p.add_ld + nlog;
+    const f32x4 a0 = *(const f32x4*)ad, a1 = *(const f32x4*)(ad + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] += a0[e]; v[4 + e] += a1[e]; }
+  }
+}
+
+// split-K reduce + epilogue for the row-major, 16-byte-aligned case: one thread per 8 output
+// columns (the launches this serves are the 4x4 / 8x8 convolutions: it is pure slab traffic)
+__global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(GemmArgs p) {
+  const bool geglu = p.act == LDM_ACT_GEGLU;
+  const int nout = geglu ? p.N / 2 : p.N;
+  const int pcols = nout / 8;
+  const int64_t total = (int64_t)p.M * pcols;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * 256) {
+    const int m = (int)(idx / pcols), c = (int)(idx - (int64_t)m * pcols) * 8;
+    const int nlog = geglu ? (c >> 5) * 64 + (c & 31) : c;
+    float v[8];
+    splitk_sum8(p, m, nlog, v);
+    if (geglu) {
+      float g[8];
+      splitk_sum8(p, m, nlog + 32, g);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= gelu_erf_f(g[e]);
+    } else if (p.act != LDM_ACT_NONE) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = apply_act(p.act, v[e]);
+    }
+    const int64_t ooff = (int64_t)m * p.ldc_m + c;
+    const int64_t roff = (int64_t)m * p.ldr + c;
+    if (p.out_dtype == LDM_BF16) {
+      if (p.residual) {
+        float rr[8];
+        chunk_to_f32(*(const u32x4*)((const bf16_t*)p.residual + roff), rr, bf16_t());
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rr[e];
+      }
+      *(u32x4*)((bf16_t*)p.out + ooff) = f32_to_chunk(v, bf16_t());
+    } else {
+      if (p.residual) {
+        const f32x4 r0 = *(const f32x4*)((const float*)p.residual + roff);
+        const f32x4 r1 = *(const f32x4*)((const float*)p.residual + roff + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+      }
+      f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+      *(f32x4*)((float*)p.out + ooff) = o0;
+      *(f32x4*)((float*)p.out + ooff + 4) = o1;
+    }
+  }
+}
+
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
 constexpr int kNumTiles = 9;
@@ -709,10 +809,12 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   int st = ldm_launch_status("ldm_gemm");
   if (st != LDM_OK) return st;
   if (split > 1) {
-    int64_t total = (int64_t)p->M * nout;
+    const bool vec = a.vec_epilogue && al(p->workspace, 16) && p->N % 4 == 0;
+    int64_t total = vec ? (int64_t)p->M * (nout / 8) : (int64_t)p->M * nout;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a);
+    if (vec) hipLaunchKernelGGL(splitk_epilogue_vec_kernel, dim3(blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a);
     st = ldm_launch_status("ldm_gemm(splitk epilogue)");
   }
   return st;
