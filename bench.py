@@ -16,8 +16,9 @@ no checkpoints, no datasets).  Weak scaling: every GPU samples its own 16 images
 Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
   roofline     : the MFMA GEMM/implicit-conv kernel family (dominant kernel):
                  algorithmic FLOPs per U-Net step in that family / its summed launch
-                 time per step, measured with HIP events around every launch on the
-                 launch stream in one instrumented (non-graph) step after the timed region.
+                 time per step = (replay time of the captured step) - (replay time of the
+                 same step captured without the family's launches), HIP events on the
+                 launch stream over 10 replays each, after the timed region.
   cpu_baseline : the CPU oracle (a port of the reference arithmetic; TensorFlow is not
                  installable here) timed on the host cores on a bounded sample.
 """
@@ -198,32 +199,73 @@ def main():
   assert tuple(out.shape) == (world * B, 8 * args.latent, 8 * args.latent, 3)
   assert bool(torch.isfinite(out).all()), "non-finite images"
 
-  # ---- instrumented step: HIP events around every MFMA GEMM/conv launch --------------
+  # ---- the MFMA GEMM/conv family's share of a step -------------------------------------
+  # Two captured HIP graphs of the SAME step, one with every ldm_gemm launch left out
+  # (ops.set_gemm_skip), each timed with HIP events over 10 back-to-back replays on the launch
+  # stream: family time = full - without.  In a graph the kernels run back to back (their
+  # summed rocprof durations equal the replay time), so this agrees with the rocprofv3
+  # kernel-trace average in profiles/ and carries no per-launch event overhead.  The older
+  # per-launch event brackets (eager step) are kept as `ms_per_unet_step_event_brackets`.
   R = 2 * B
-  timers = []
   sampler._index_dev.fill_(args.ddim_steps - 1)
-  if sampler._graph is not None:
-    # keep the GPU busy (three queued graph replays) while the host enqueues the
-    # instrumented step: its kernels and events then execute back to back, so an event
-    # pair brackets the kernel alone and not the host's launch latency
+
+  def captured_step(skip_counter):
+    ops.set_gemm_skip(skip_counter)
+    try:
+      g = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(g):
+        sampler._step(args.guidance, False, None, dec_index=False)
+    finally:
+      ops.set_gemm_skip(None)
+    return g
+
+  def replay_ms(g, reps=10):
     for _ in range(3):
+      g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+      g.replay()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+  skipped = [0]
+  g_full, g_rest = captured_step(None), captured_step(skipped)
+  t_full, t_rest = replay_ms(g_full), replay_ms(g_rest)
+  gemm_ms = t_full - t_rest
+  n_launches = skipped[0]
+  del g_full, g_rest
+  timers = []
+  if sampler._graph is not None:
+    for _ in range(3):          # keep the GPU busy while the host enqueues the bracketed step
       sampler._graph.replay()
-    sampler._index_dev.fill_(args.ddim_steps - 1)
+  sampler._index_dev.fill_(args.ddim_steps - 1)
   ops.set_gemm_timer(timers)
   sampler._step(args.guidance, False, None, dec_index=False)
   torch.cuda.synchronize()
   ops.set_gemm_timer(None)
-  gemm_ms = sum(a.elapsed_time(b) for a, b in timers)
+  bracket_ms = sum(x.elapsed_time(y) for x, y in timers)
   lat = args.latent
   gf_family = (GF_CONV_ROW.get(lat, 0) + GF_GEMM_ROW.get(lat, 0) - GF_CTX_KV_ROW) * R if lat in GF_CONV_ROW else None
   roofline = None
   if gf_family:
     achieved = gf_family / gemm_ms          # GFLOP / ms = TFLOP/s
     peak = PEAK_TFLOPS[args.dtype]
+    # HBM-side bytes of the family per U-Net step from the committed PMC passes (same workload;
+    # separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE correction applied by tools/pmc_family.py)
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if args.dtype == "bf16" and lat == 32 and B == 16 and os.path.isfile(tj):
+      traffic = json.load(open(tj)).get("hbm_bytes_per_eval")
     roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
+                "frac": achieved / peak, "traffic": traffic,
+                "traffic_unit": "HBM bytes per U-Net step for this kernel family (PMC, profiles/r01_pmc_traffic.json)",
                 "kernel": "gemm_kernel<T,BM,BN,WM,WN> (Dense/1x1/projection GEMMs + implicit-GEMM 3x3 convs)",
-                "launches_per_unet_step": len(timers), "ms_per_unet_step_in_kernel": gemm_ms,
+                "launches_per_unet_step": n_launches, "ms_per_unet_step_in_kernel": gemm_ms,
+                "avg_launch_us": gemm_ms * 1e3 / max(n_launches, 1),
+                "ms_unet_step_graph_full": t_full, "ms_unet_step_graph_without_family": t_rest,
+                "ms_per_unet_step_event_brackets": bracket_ms,
                 "algorithmic_gflop_per_unet_step": gf_family}
 
   if rank == 0:

@@ -382,6 +382,12 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const T* __restrict__ x, i
     v[k] = z;
     if (active && p < HW) v[k] = *(const u32x4*)(xb + (int64_t)p * ldx);
   }
+  float gm[EPC], bt[EPC];                           // fetched now: off the post-reduction critical path
+#pragma unroll
+  for (int e = 0; e < EPC; ++e) {
+    gm[e] = active ? gamma[c0 + e] : 0.f;
+    bt[e] = active ? beta[c0 + e] : 0.f;
+  }
 
   // fixed-order block reduction of a (lo, hi) pair per thread -> s_red[g], g < GB
   auto reduce_groups = [&](float lo, float hi) {
@@ -446,8 +452,8 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const T* __restrict__ x, i
 #pragma unroll
     for (int e = 0; e < EPC; ++e) {
       mu[e] = e < nlo ? m_lo : m_hi;
-      sc[e] = (e < nlo ? r_lo : r_hi) * gamma[c0 + e];
-      sh[e] = beta[c0 + e];
+      sc[e] = (e < nlo ? r_lo : r_hi) * gm[e];
+      sh[e] = bt[e];
     }
   }
   T* ob = out + (int64_t)b * HW * ldo + c0;

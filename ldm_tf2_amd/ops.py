@@ -90,7 +90,23 @@ def set_gemm_timer(sink):
   _GEMM_TIMER = sink
 
 
+_GEMM_SKIP = None
+
+
+def set_gemm_skip(counter):
+  """Measurement hook (bench.py): while `counter` is a one-element list, ldm_gemm launches are
+  NOT enqueued (only counted in counter[0]).  bench.py captures one U-Net step this way and
+  times it against the full step: the difference is the MFMA GEMM/conv family's share of a
+  step, measured with HIP events on graph replays (no per-launch event overhead).  Outputs of
+  such a step are garbage by construction; never set outside a measurement."""
+  global _GEMM_SKIP
+  _GEMM_SKIP = counter
+
+
 def _gemm(p: GemmParams, device):
+  if _GEMM_SKIP is not None:
+    _GEMM_SKIP[0] += 1
+    return
   ws = workspace(device)
   p.workspace = ws.data_ptr()
   p.workspace_bytes = ws.numel()

@@ -28,6 +28,8 @@ def main():
   tot = sum(float(r["TotalDurationNs"]) for r in rows)
   evals = sum(int(r["Calls"]) for r in rows if "time_embedding_kernel" in r["Name"])
   gemm = [r for r in rows if "gemm_kernel<" in r["Name"]]
+  red = [r for r in rows if "splitk_epilogue" in r["Name"]]
+  red_ns = sum(float(r["TotalDurationNs"]) for r in red)
   gemm_ns = sum(float(r["TotalDurationNs"]) for r in gemm)
   gemm_calls = sum(int(r["Calls"]) for r in gemm)
   print("# rocprofv3 --kernel-trace --stats summary\n")
@@ -38,6 +40,9 @@ def main():
           f"{gemm_calls} launches = **{gemm_ns / 1e6 / evals:.3f} ms per U-Net evaluation** "
           f"(incl. the text encoder's and decoder's launches, which add a few %), "
           f"average launch {gemm_ns / 1e3 / max(gemm_calls, 1):.1f} us")
+    print(f"* the family as bench.py's `roofline` defines it (every launch made by `ldm_gemm`: `gemm_kernel<...>` "
+          f"+ its split-K reduce `splitk_epilogue*`): **{(gemm_ns + red_ns) / 1e6 / evals:.3f} ms per U-Net evaluation**, "
+          f"{(gemm_calls + sum(int(r['Calls']) for r in red)) / evals:.0f} kernel launches per evaluation")
     print(f"* all kernels: {tot / 1e6 / evals:.3f} ms per U-Net evaluation (upper bound: includes text encoder + decoder)")
   if args.bench_json:
     for line in open(args.bench_json):
@@ -47,7 +52,7 @@ def main():
         r = b.get("roofline") or {}
         print(f"* bench.py line of the same command: value {b['value']:.3f} {b['unit']}, "
               f"{b.get('ms_per_unet_step', 0):.3f} ms per U-Net step (HIP events around the graph replays), "
-              f"gemm family {r.get('ms_per_unet_step_in_kernel', 0):.3f} ms per step by HIP events "
+              f"ldm_gemm family {r.get('ms_per_unet_step_in_kernel', 0):.3f} ms per step by HIP events (graph-replay difference) "
               f"-> {r.get('achieved', 0):.0f} TFLOP/s = {100 * r.get('frac', 0):.1f}% of {r.get('peak')} TFLOP/s")
   print("\n| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|")
   for r in rows[:args.top]:
