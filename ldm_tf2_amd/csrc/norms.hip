@@ -328,12 +328,19 @@ inline bool gn_fused_plan(int B, int HW, int C, int G, int esize, GnFusedPlan* p
   for (int g = 1; g <= 8; g *= 2)
     if (G % g == 0 && (g * cpg) % epc == 0) { GB = g; break; }
   if (!GB) return false;
-  // tiny images: more groups per workgroup while the grid still covers the chip
-  while (GB * 2 <= 8 && G % (GB * 2) == 0 && (int64_t)HW * (GB * cpg / epc) < 1024 &&
-         (int64_t)B * (G / (GB * 2)) >= 256)
-    GB *= 2;
   const int S = GB * cpg / epc;
   if (S > 64) return false;
+  // small slabs: ONE wave per workgroup (block barriers degenerate, reductions are pure
+  // butterflies), up to 24 chunks per lane
+  // (measured: pays when the launch still has >= 2 waves per CU at <= 16 chunks per lane, or
+  // >= 4 per CU at <= 24)
+  {
+    const int need = (HW + 64 / S - 1) / (64 / S);
+    const int64_t waves = (int64_t)B * (G / GB);
+    if (need <= 8 && waves >= 512) { *pl = {GB, S, 64, 8}; return true; }
+    if (need <= 16 && waves >= 512) { *pl = {GB, S, 64, 16}; return true; }
+    if (need <= 24 && waves >= 1024) { *pl = {GB, S, 64, 24}; return true; }
+  }
   // few chunks per thread (register budget: 4 VGPRs each), more threads before more chunks
   for (int NT : {256, 512, 1024}) {
     const int need = (HW + NT / S - 1) / (NT / S);
@@ -348,7 +355,7 @@ inline bool gn_fused_plan(int B, int HW, int C, int G, int esize, GnFusedPlan* p
 }
 
 template <typename T, int NT, int MAXCH>
-__global__ __launch_bounds__(NT) void gn_fused_kernel(const T* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(NT, ((MAXCH <= 8 || (MAXCH <= 16 && NT > 64)) ? 4 : 2)) void gn_fused_kernel(const T* __restrict__ x, int64_t ldx,
                                                       const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
                                                       T* __restrict__ out, int64_t ldo, int B, int HW,
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const T* __restrict__ x, i
                                                       int do_silu) {
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int NW = NT / 64;
-  __shared__ float s_part[NT][2];
+  __shared__ float s_part[NT == 64 ? 1 : NT][2];
   __shared__ float s_tot[64][2];
   __shared__ float s_red[8], s_mean[8], s_rstd[8];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -390,27 +397,40 @@ __global__ __launch_bounds__(NT) void gn_fused_kernel(const T* __restrict__ x, i
   }
 
   // fixed-order block reduction of a (lo, hi) pair per thread -> s_red[g], g < GB
+  // (a lane's lo belongs to group g_lo, its hi to g_lo + 1): per group one wave butterfly over
+  // the lanes' selected contributions, then the waves' partials are added in wave order
   auto reduce_groups = [&](float lo, float hi) {
-    s_part[tid][0] = lo; s_part[tid][1] = hi;
-    __syncthreads();
-    for (int c = wave; c < S; c += NW) {
-      float a0 = 0.f, a1 = 0.f;
-      for (int q = lane; q < P; q += 64) { a0 += s_part[q * S + c][0]; a1 += s_part[q * S + c][1]; }
-      a0 = wave_sum(a0); a1 = wave_sum(a1);
-      if (lane == 0) { s_tot[c][0] = a0; s_tot[c][1] = a1; }
-    }
-    __syncthreads();
-    if (tid < GB) {
-      float t = 0.f;
-      for (int c = 0; c < S; ++c) {
-        const int ec = c * EPC, gl = ec / cpg;
-        const int nl = min(EPC, (gl + 1) * cpg - ec);
-        if (gl == tid) t += s_tot[c][0];
-        if (nl < EPC && gl + 1 == tid) t += s_tot[c][1];
+    if constexpr (NT == 64) {
+      for (int g = 0; g < GB; ++g) {
+        const float mine = (g == g_lo ? lo : 0.f) + (g == g_lo + 1 ? hi : 0.f);
+        const float t = wave_sum(mine);
+        if (lane == 0) s_red[g] = t;
       }
-      s_red[tid] = t;
+      __syncthreads();
+    } else {
+      // multi-wave workgroups: per chunk column (fixed lo/hi split) over the pixel lanes, then
+      // the columns of each group
+      s_part[tid][0] = lo; s_part[tid][1] = hi;
+      __syncthreads();
+      for (int c = wave; c < S; c += NW) {
+        float a0 = 0.f, a1 = 0.f;
+        for (int q = lane; q < P; q += 64) { a0 += s_part[q * S + c][0]; a1 += s_part[q * S + c][1]; }
+        a0 = wave_sum(a0); a1 = wave_sum(a1);
+        if (lane == 0) { s_tot[c][0] = a0; s_tot[c][1] = a1; }
+      }
+      __syncthreads();
+      if (tid < GB) {
+        float t = 0.f;
+        for (int c = 0; c < S; ++c) {
+          const int ec = c * EPC, gl = ec / cpg;
+          const int nl = min(EPC, (gl + 1) * cpg - ec);
+          if (gl == tid) t += s_tot[c][0];
+          if (nl < EPC && gl + 1 == tid) t += s_tot[c][1];
+        }
+        s_red[tid] = t;
+      }
+      __syncthreads();
     }
-    __syncthreads();
   };
 
   const float n = (float)HW * (float)cpg;
@@ -479,7 +499,8 @@ void gn_fused_launch(const GnFusedPlan& pl, dim3 grid, hipStream_t s, const void
 #define GNF(NT_, MC_)                                                                                  \
   hipLaunchKernelGGL((gn_fused_kernel<T, NT_, MC_>), grid, dim3(NT_), 0, s, (const T*)x, ldx, gamma,   \
                      beta, (T*)out, ldo, B, HW, C, G, pl.GB, pl.S, eps, silu)
-  if (pl.NT == 256) { if (pl.maxch == 8) GNF(256, 8); else if (pl.maxch == 16) GNF(256, 16); else GNF(256, 24); }
+  if (pl.NT == 64) { if (pl.maxch == 8) GNF(64, 8); else if (pl.maxch == 16) GNF(64, 16); else GNF(64, 24); }
+  else if (pl.NT == 256) { if (pl.maxch == 8) GNF(256, 8); else if (pl.maxch == 16) GNF(256, 16); else GNF(256, 24); }
   else if (pl.NT == 512) { if (pl.maxch == 8) GNF(512, 8); else if (pl.maxch == 16) GNF(512, 16); else GNF(512, 24); }
   else { if (pl.maxch == 8) GNF(1024, 8); else GNF(1024, 16); }
 #undef GNF

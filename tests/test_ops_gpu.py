@@ -209,7 +209,10 @@ def test_groupnorm(dev, dtype, shape, silu):
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("shape", [(3, 32, 32, 320), (9, 16, 16, 640), (2, 8, 8, 1280), (5, 4, 4, 1280),
                                    (2, 8, 8, 2560), (2, 16, 16, 1920), (1, 32, 32, 960), (2, 32, 32, 640),
-                                   (2, 64, 64, 320), (2, 5, 7, 320)])
+                                   (2, 64, 64, 320), (2, 5, 7, 320),
+                                   # one-wave-per-slab variants (taken when the launch has >= 512 waves)
+                                   (32, 8, 8, 1280), (32, 4, 4, 2560), (32, 8, 8, 1920), (32, 16, 16, 1280),
+                                   (33, 8, 8, 640)])
 def test_groupnorm_single_launch(dev, dtype, shape):
   """The register-resident single-launch kernel (every U-Net GroupNorm shape) against the
   oracle, against the two-launch path, and run-to-run identical (fixed-order reductions)."""
