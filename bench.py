@@ -213,7 +213,7 @@ def main():
     ops.set_gemm_skip(skip_counter)
     try:
       g = torch.cuda.CUDAGraph()
-      with torch.cuda.graph(g):
+      with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog thread may be live
         sampler._step(args.guidance, False, None, dec_index=False)
     finally:
       ops.set_gemm_skip(None)

@@ -242,7 +242,9 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
         self._x2[:B].copy_(xt)
         self._x2[B:].copy_(xt)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread-local capture mode: in a multi-GPU job the RCCL watchdog thread polls events
+        # while this thread captures; only this thread's calls belong to the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
           self._step(guidance_scale, False, noise_table, dec_index=True)
         self._graph, self._graph_key = g, gkey
         self._xt.copy_(xt)
