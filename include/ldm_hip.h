@@ -112,9 +112,22 @@ typedef struct {
    * stride 2, unet.py:26-27); 1 = none before, one after -- the autoencoder's
    * pad [[0,1],[0,1]] + stride-2 VALID downsample (autoencoder.py:133-136); stride 2 only. */
   int32_t no_lead_pad;
+  /* Second output: LayerNormalization of the row just written (unet.py:309-313: every
+   * residual-stream update of the BasicTransformerBlock is followed by a LayerNorm whose output
+   * feeds the next projection).  ln_out[m][:] = LN(out[m][:]) * ln_gamma + ln_beta over all N
+   * columns, computed from the values as stored (i.e. after rounding to out_dtype), same dtype
+   * as out, row stride ld_ln.  Needs a tile that holds whole rows: plain rows, batch 1,
+   * N == 320, row-major 16-byte-aligned output, no GEGLU (ldm_gemm_ln_supported).  NULL = off. */
+  void* ln_out;
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t ld_ln;
+  float ln_eps;
 } ldm_gemm_params;
 
 int ldm_gemm(const ldm_gemm_params* p, void* stream);
+/* 1 if ldm_gemm accepts ln_out for a [M][N] output of this dtype (host query) */
+int ldm_gemm_ln_supported(int N, int dtype);
 /* the tile configuration and split-K factor ldm_gemm would pick for these params (host only;
  * nothing is launched) -- for tools and tests of the cost model */
 int ldm_gemm_plan(const ldm_gemm_params* p, int* tile, int* split_k);

@@ -32,6 +32,7 @@ class GemmParams(C.Structure):
       ("act", c_i32), ("dtype", c_i32), ("out_dtype", c_i32), ("split_k", c_i32),
       ("tile", c_i32), ("alpha", c_f32),
       ("a_scale", c_vp), ("a_shift", c_vp), ("a_silu", c_i32), ("no_lead_pad", c_i32),
+      ("ln_out", c_vp), ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ld_ln", c_i64), ("ln_eps", c_f32),
   ]
 
 
@@ -68,6 +69,7 @@ SIGNATURES = {
     "ldm_groupnorm_fused": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_f32,
                                     c_i32, c_i32, c_vp]),
     "ldm_gemm_plan": (c_i32, [c_vp, c_vp, c_vp]),
+    "ldm_gemm_ln_supported": (c_i32, [c_i32, c_i32]),
     "ldm_gaussian_sample": (c_i32, [c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_vp]),
     "ldm_vq_nearest": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp]),
     "ldm_embedding": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),

@@ -57,7 +57,14 @@ struct GemmArgs {
   int vec_epilogue;
   int debug;   // ablation switches (LDM_GEMM_DEBUG env): 1 = no in-loop loads, 2 = no MFMA, 4 = no barrier
   float alpha;
+  char* ln_out;              // second output: LayerNorm of the stored rows (whole-row tiles only)
+  const float* ln_gamma;
+  const float* ln_beta;
+  int64_t ld_ln;
+  float ln_eps;
 };
+
+constexpr int kLnTile = 8;   // the tile whose BN (320) holds a whole row of the N = 320 layers
 
 constexpr uint32_t kOOB = 0x80000000u;   // >= any num_records we accept: load returns 0
 
@@ -431,6 +438,58 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
         *(f32x4*)((float*)p.out + ooff) = o0;
         *(f32x4*)((float*)p.out + ooff + 4) = o1;
       }
+      if (p.ln_out) {
+        // keep the row AS STORED (rounded to the output dtype) for the LayerNorm pass below
+        if (p.out_dtype == LDM_BF16) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e]));
+        }
+        f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(f32x4*)(sC + row * BN + lcol) = o0;
+        *(f32x4*)(sC + row * BN + lcol + 4) = o1;
+      }
+    }
+    if (p.ln_out) {
+      // second output: LayerNorm of the rows of this pass.  The host only sets ln_out when the
+      // tile holds whole rows (n0 == 0, N == BN); one wave per row, 8 columns per lane.
+      __syncthreads();
+      const bool act = lane < BN / 8;
+      float gm[8], bt[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { gm[e] = act ? p.ln_gamma[lane * 8 + e] : 0.f; bt[e] = act ? p.ln_beta[lane * 8 + e] : 0.f; }
+      for (int row = wave; row < EROWS; row += NW) {
+        const int m = m0 + ep * EROWS + row;
+        if (m >= p.M) break;                        // wave-uniform
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        if (act) {
+          const f32x4 x0 = *(const f32x4*)(sC + row * BN + lane * 8), x1 = *(const f32x4*)(sC + row * BN + lane * 8 + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { f[e] = x0[e]; f[4 + e] = x1[e]; }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e];
+        const float mean = wave_sum(s) * (1.0f / BN);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += act ? d * d : 0.f; }
+        const float rstd = rsqrtf(wave_sum(q) * (1.0f / BN) + p.ln_eps);
+        if (act) {
+          float y[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) y[e] = (f[e] - mean) * rstd * gm[e] + bt[e];
+          const int64_t loff = (int64_t)m * p.ld_ln + lane * 8;
+          if (p.out_dtype == LDM_BF16) {
+            *(u32x4*)((bf16_t*)p.ln_out + loff) = f32_to_chunk(y, bf16_t());
+          } else {
+            f32x4 o0 = {y[0], y[1], y[2], y[3]}, o1 = {y[4], y[5], y[6], y[7]};
+            *(f32x4*)((float*)p.ln_out + loff) = o0;
+            *(f32x4*)((float*)p.ln_out + loff + 4) = o1;
+          }
+        }
+      }
     }
    }
     return;
@@ -697,6 +756,10 @@ extern "C" size_t ldm_gemm_workspace_bytes(const ldm_gemm_params* p) {
   return split > 1 ? (size_t)split * p->M * p->N * 4 : 0;
 }
 
+extern "C" int ldm_gemm_ln_supported(int N, int dtype) {
+  return (N == kTiles[kLnTile].bn && (dtype == LDM_F32 || dtype == LDM_BF16)) ? 1 : 0;
+}
+
 extern "C" int ldm_gemm_plan(const ldm_gemm_params* p, int* tile, int* split_k) {
   LDM_CHECK_ARG(p && tile && split_k, "ldm_gemm_plan: null pointer");
   LDM_CHECK_ARG(p->dtype == LDM_F32 || p->dtype == LDM_BF16, "ldm_gemm_plan: bad dtype %d", p->dtype);
@@ -762,6 +825,15 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
 
   int cfg, split;
   choose(p, esize, &cfg, &split);
+  if (p->ln_out) {
+    LDM_CHECK_ARG(!p->conv && p->batch == 1 && p->act != LDM_ACT_GEGLU && p->ldc_n == 1 &&
+                      ldm_gemm_ln_supported(p->N, p->out_dtype) && p->ln_gamma && p->ln_beta,
+                  "ldm_gemm: ln_out needs plain rows, batch 1, no GEGLU, N == %d and gamma/beta", kTiles[kLnTile].bn);
+    LDM_CHECK_ARG(p->ld_ln % 8 == 0 && ((uintptr_t)p->ln_out % 16) == 0 && ((uintptr_t)p->ln_gamma % 16) == 0 &&
+                      ((uintptr_t)p->ln_beta % 16) == 0, "ldm_gemm: ln_out / gamma / beta alignment");
+    cfg = kLnTile;
+    split = 1;
+  }
   if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5, "ldm_gemm: GEGLU needs tile 1, 2 or 5");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -775,6 +847,8 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   a.conv = p->conv; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.OH = p->OH; a.OW = p->OW;
   a.stride = p->stride; a.upsample = p->upsample; a.pad = p->no_lead_pad ? 0 : 1; a.act = p->act; a.out_dtype = p->out_dtype;
   a.alpha = p->alpha;
+  a.ln_out = (char*)p->ln_out; a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_beta; a.ld_ln = p->ld_ln;
+  a.ln_eps = p->ln_eps;
   // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
   const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
   auto al = [](const void* q, int by) { return ((uintptr_t)q % by) == 0; };
@@ -784,6 +858,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
       (!p->residual || (p->ldr % 8 == 0 && p->stride_r % 8 == 0 && al(p->residual, 16))) &&
       (!p->bias || al(p->bias, 16)) &&
       (!p->addend || (al(p->addend, 16) && p->add_ld % 4 == 0));
+  if (p->ln_out) LDM_CHECK_ARG(a.vec_epilogue, "ldm_gemm: ln_out needs the 16-byte-aligned row-major epilogue");
   a.ktiles = cdiv(p->K, bke);
   a.split_k = split;
   a.ktiles_per_split = cdiv(a.ktiles, split);

@@ -120,10 +120,16 @@ def _gemm(p: GemmParams, device):
   _GEMM_TIMER.append((e0, e1))
 
 
+def linear_ln_supported(n_out, dtype):
+  """True if `linear(..., ln=...)` can emit the LayerNorm of its output rows in the same launch."""
+  return bool(lib.ldm_gemm_ln_supported(int(n_out), code(dtype)))
+
+
 def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_rows=0,
-           alpha=1.0, tile=0, split_k=0):
+           alpha=1.0, tile=0, split_k=0, ln=None):
   """out[..., n] = act(alpha * x[..., :] . wt[n, :] + bias[n] + addend[group]) + residual.
-  x [..., K]; wt [N, K] contiguous; out [..., N] (N/2 wide for GEGLU)."""
+  x [..., K]; wt [N, K] contiguous; out [..., N] (N/2 wide for GEGLU).
+  `ln=(gamma, beta, ln_out, eps)`: also writes ln_out = LayerNorm(out) (same shape/dtype)."""
   K = x.shape[-1]
   N = wt.shape[0]
   M = x.numel() // K
@@ -143,6 +149,11 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
     p.add_ld = addend.stride(0) if (addend.dim() == 2 and addend.shape[0] > 1) else 0
   p.act, p.dtype, p.out_dtype, p.alpha = act, code(x.dtype), code(out.dtype), alpha
   p.tile, p.split_k = tile, split_k
+  if ln is not None:
+    gamma, beta, ln_out, eps = ln
+    assert ln_out.dtype == out.dtype and tuple(ln_out.shape) == tuple(out.shape)
+    p.ln_out, p.ld_ln, p.ln_eps = _ptr(ln_out), row_ld(ln_out), float(eps)
+    p.ln_gamma, p.ln_beta = _ptr(_f32(gamma, "ln gamma")), _ptr(_f32(beta, "ln beta"))
   _gemm(p, x.device)
   return out
 

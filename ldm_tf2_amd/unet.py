@@ -22,6 +22,8 @@ changes results beyond float rounding order):
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import layout as L
@@ -88,13 +90,18 @@ class UNet:
   def __init__(self, model_channels=320, out_channels=4, num_blocks=2,
                attention_resolutions=(4, 2, 1), dropout_rate=0.1, channel_mult=(1, 2, 4, 4),
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
-               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False):
+               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
     # the VALU), which costs more than the one streaming pass it removes.  Kept as an
     # option (parity-tested) for wider-N tiles in a later round.
     self.fuse_groupnorm = fuse_groupnorm
+    # fuse_layernorm: the transformer blocks' LayerNorms come out of the producing GEMM's epilogue
+    # where its tile holds whole rows (C = 320).  Measured on MI355X at R=32: 11.02 vs 10.95 ms per
+    # step -- the whole-row 128x320 tile (one workgroup per CU) plus the extra epilogue pass cost
+    # slightly more than the 15 LayerNorm launches they replace.  Opt-in (parity-tested).
+    self._fuse_ln = bool(fuse_layernorm) or os.environ.get("LDM_FUSED_LN") is not None
     self._fuse_cache = {}
     self._model_channels = model_channels
     self._out_channels = out_channels
@@ -233,10 +240,15 @@ class UNet:
     t0 = B_.get("gn", (R, h, w, c), dt)
     ops.groupnorm(x, st.gn[0], st.gn[1], t0, GN_EPS_ST, silu=False, partial=self._gnp)
     ha = B_.get("st_a", (R, T, c), dt)
-    ops.linear(t0, st.proj_in[0], ha, bias=st.proj_in[1])
     ln = B_.get("st_ln", (R, T, c), dt)
+    # each LayerNorm of the block normalises a row the preceding projection has just produced:
+    # where the GEMM tile holds whole rows (C = 320) it is emitted by that GEMM's epilogue
+    fuse_ln = self._fuse_ln and ops.linear_ln_supported(c, dt)
+    lnp = lambda i: (st.ln[i][0], st.ln[i][1], ln, LN_EPS) if fuse_ln else None
+    ops.linear(t0, st.proj_in[0], ha, bias=st.proj_in[1], ln=lnp(0))
     # self-attention (unet.py:309-310)
-    ops.layernorm(ha, st.ln[0][0], st.ln[0][1], ln, LN_EPS)
+    if not fuse_ln:
+      ops.layernorm(ha, st.ln[0][0], st.ln[0][1], ln, LN_EPS)
     qk = B_.get("st_qk", (R, T, 2 * hs), dt)
     ops.linear(ln, st.qk1, qk)
     tp = (T + 7) // 8 * 8
@@ -245,15 +257,17 @@ class UNet:
     att = B_.get("st_att", (R, T, hs), dt)
     ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale)
     hb = B_.get("st_b", (R, T, c), dt)
-    ops.linear(att, st.o1[0], hb, bias=st.o1[1], residual=ha)
+    ops.linear(att, st.o1[0], hb, bias=st.o1[1], residual=ha, ln=lnp(1))
     # cross-attention (unet.py:311-312)
-    ops.layernorm(hb, st.ln[1][0], st.ln[1][1], ln, LN_EPS)
+    if not fuse_ln:
+      ops.layernorm(hb, st.ln[1][0], st.ln[1][1], ln, LN_EPS)
     q = B_.get("st_q", (R, T, hs), dt)
     ops.linear(ln, st.q2, q)
     ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale)
-    ops.linear(att, st.o2[0], ha, bias=st.o2[1], residual=hb)
+    ops.linear(att, st.o2[0], ha, bias=st.o2[1], residual=hb, ln=lnp(2))
     # GEGLU feed-forward (unet.py:313, :323-325, :335-338)
-    ops.layernorm(ha, st.ln[2][0], st.ln[2][1], ln, LN_EPS)
+    if not fuse_ln:
+      ops.layernorm(ha, st.ln[2][0], st.ln[2][1], ln, LN_EPS)
     ff = B_.get("st_ff", (R, T, 4 * c), dt)
     ops.linear(ln, st.geglu[0], ff, bias=st.geglu[1], act=ops.ACT_GEGLU)
     ops.linear(ff, st.ff_out[0], hb, bias=st.ff_out[1], residual=ha)

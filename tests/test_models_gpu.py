@@ -239,3 +239,25 @@ def test_progressive_sampling(dev, unet_w, txt_w, kl_w):
   # the final images equal the plain loop's
   plain = s.ddim_p_sample_loop(ids, [B, 16, 16, 4], 5., x_T=x_T, noises=noises)
   assert rel_err(plain, gi.cpu())[0] < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
+def test_unet_forward_fused_layernorm(dev, dtype):
+  """LayerNorms emitted by the producing GEMM's epilogue (opt-in; C = 320 blocks) give the same U-Net."""
+  from ldm_tf2_amd.unet import UNet
+  cfg = dict(model_channels=320, out_channels=4, num_blocks=1, channel_mult=(1, 2), num_heads=8)
+  w = Wt.init_weights(Wt.unet_manifest(context_dim=CTX_DIM, **cfg), seed=3, mode="random", scope="unet")
+  g = np.random.default_rng(5)
+  x = g.standard_normal((2, 16, 16, 4)).astype(np.float32)
+  ctx = g.standard_normal((2, 77, CTX_DIM)).astype(np.float32)
+  t = np.array([981, 21], dtype=np.int32)
+  ref = O.unet_forward(x, t, ctx, w)
+  outs = []
+  for fuse in (True, False):
+    unet = UNet(**cfg, weights=w, dtype=dtype, device=dev, context_dim=CTX_DIM, fuse_layernorm=fuse)
+    assert unet._fuse_ln == fuse
+    got = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
+    check(got, ref, dtype, f"unet (fused LayerNorm={fuse})")
+    outs.append(got.float().cpu())
+  if dtype == torch.float32:
+    assert (outs[0] - outs[1]).abs().max().item() < 1e-4

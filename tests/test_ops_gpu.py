@@ -412,3 +412,34 @@ def test_error_reporting(dev):
   with pytest.raises(LdmHipError):
     o.conv3x3(torch.zeros(1, 4, 4, 20, device=dev), torch.zeros(8, 180, device=dev),
               torch.zeros(1, 4, 4, 8, device=dev))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("M,K", [(300, 320), (1024, 128), (77, 1280)])
+def test_linear_with_layernorm_output(dev, dtype, M, K):
+  """ldm_gemm's second output: LayerNorm (unet.py:309-313) of the row it has just stored."""
+  o = ops()
+  N = 320
+  assert o.linear_ln_supported(N, dtype) and not o.linear_ln_supported(640, dtype)
+  x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+  bias, res = rnd((N,), torch.float32, 3), rnd((M, N), dtype, 4) * 2 + 0.7
+  gamma, beta = rnd((N,), torch.float32, 5) * 0.2 + 1, rnd((N,), torch.float32, 6) * 0.2
+  out = torch.full((M, N), float("nan"), dtype=dtype, device=dev)
+  lnb = torch.full((M, N + 64), float("nan"), dtype=dtype, device=dev)
+  ln_out = lnb[:, 64:]                                     # strided second output
+  o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), residual=res.to(dev),
+           ln=(gamma.to(dev), beta.to(dev), ln_out, 1e-5))
+  torch.cuda.synchronize()
+  ref = x.float() @ w.float().t() + bias + res.float()
+  close(out, ref, dtype)
+  # the LayerNorm is of the row AS STORED: identical to a separate ldm_layernorm of `out`
+  sep = torch.empty(M, N, dtype=dtype, device=dev)
+  o.layernorm(out, gamma.to(dev), beta.to(dev), sep, 1e-5)
+  torch.cuda.synchronize()
+  close(ln_out, O.layer_norm(out.float().cpu(), gamma, beta), dtype, scale=2.0)
+  assert (ln_out.float() - sep.float()).abs().max().item() <= (2e-5 if dtype == torch.float32 else 4e-2)
+  assert torch.isnan(lnb[:, :64].float()).all()
+  from ldm_tf2_amd._lib import LdmHipError
+  with pytest.raises(LdmHipError):                         # a tile cannot hold a 640-wide row: loud error
+    o.linear(x.to(dev), rnd((640, K), dtype, 2).to(dev), torch.empty(M, 640, dtype=dtype, device=dev),
+             ln=(torch.ones(640, device=dev), torch.zeros(640, device=dev), torch.empty(M, 640, dtype=dtype, device=dev), 1e-5))
