@@ -737,6 +737,10 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
       const int kps = cdiv(ktiles, split);
       const double rounds = (double)(int64_t)((tiles * split + 256.0 * kResident[c] - 1) / (256.0 * kResident[c]));
       double us = rounds * (kps + kOverheadSteps[c]) * kStepUs[c] * f32x;
+      // calibration (tools/splitk_sweep.py): when the 256x128 tiling cannot fill the chip once
+      // (small-M convolutions: 4x4 / 8x8 / 16x16 maps), two co-resident 128x128 workgroups per
+      // CU measure 5-14 % faster than one 256x128 at the same split
+      if (c == 2 && (double)cdiv(p->M, 256) * cdiv(p->N, 128) * p->batch < 256.0) us *= 0.9;
       if (split > 1) us += 3.0 + (double)p->M * p->N * 4.0 * (split + 1) / 3.0e6;   // bytes / (3 TB/s) in us
       if (us < best) { best = us; best_cfg = c; best_split = split; }
     }
