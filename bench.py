@@ -132,6 +132,8 @@ def main():
   ap.add_argument("--guidance", type=float, default=5.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--no-plans", action="store_true",
+                  help="A/B: ldm_gemm's cost-model tile/split choice only (ignore the packaged in-situ plan table)")
   ap.add_argument("--fuse-gn", action="store_true",
                   help="A/B: GroupNorm+SiLU as the halo conv's prologue instead of a separate pass")
   args = ap.parse_args()
@@ -152,6 +154,9 @@ def main():
   from ldm_tf2_amd.transformer import TransformerModel
   from ldm_tf2_amd.unet import UNet
 
+  if args.no_plans:
+    for k in list(ops.gemm_plans()):
+      ops.set_plan(k, None)
   t_build = time.perf_counter()
   cfg = FULL
   w = {
@@ -288,7 +293,7 @@ def main():
                    "latent": [lat, lat, 4], "parallelism": f"replicas x{world}, one all-gather of images"},
         "ms_per_unet_step": ms_unet_step,
         "unet_tflops": GF_UNET_ROW.get(lat, 0) * R / ms_unet_step if lat in GF_UNET_ROW else None,
-        "hip_graph": not args.no_graph,
+        "hip_graph": not args.no_graph, "gemm_plan_table_entries": len(ops.gemm_plans()),
         "roofline": roofline,
     }
     if keep_cpu:

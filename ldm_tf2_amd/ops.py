@@ -103,6 +103,89 @@ def set_gemm_skip(counter):
   _GEMM_SKIP = counter
 
 
+# ---- per-shape launch plans -----------------------------------------------------------------
+# ldm_gemm picks its tile and split-K with a cost model calibrated on isolated launches.  In
+# the real step (weights cold in HBM, activations warm in L2/Infinity Cache, neighbours
+# competing) the optimum differs on some shapes, so measured overrides can be loaded:
+# {problem key: [tile, split_k]} JSON files written by tools/tune_step_plans.py, which times
+# WHOLE captured U-Net steps while varying one shape's plan at a time.  (Timing candidates
+# launch by launch in isolation was tried and made the step slower: 11.22 -> 11.44 ms.)
+# The packaged table plans/mi355x_txt2img_f8.json is loaded at import; LDM_NO_PLANS=1 disables
+# it, LDM_GEMM_PLANS=<file> adds another.  Plans only reorder float additions.
+_PLANS = {}
+_PLAN_RECORD = None
+_TILE_DIMS = {1: (256, 128, 1), 2: (128, 128, 2), 3: (128, 64, 3), 4: (64, 64, 5), 6: (128, 160, 2),
+              7: (256, 160, 1), 8: (128, 320, 1)}       # BM, BN, resident workgroups per CU
+
+
+def plan_key(p) -> str:
+  return "M%d N%d K%d b%d conv%d H%d W%d s%d u%d nlp%d act%d dt%d odt%d" % (
+      p.M, p.N, p.K, p.batch, p.conv, p.H, p.W, p.stride, p.upsample, p.no_lead_pad, p.act, p.dtype, p.out_dtype)
+
+
+def load_plans(path):
+  """Merge a {key: [tile, split_k]} JSON file into the plan table; returns the number of entries."""
+  import json
+  with open(path) as f:
+    d = json.load(f)
+  d = d.get("plans", d)
+  for k, v in d.items():
+    _PLANS[k] = (int(v[0]), int(v[1]))
+  return len(d)
+
+
+def set_plan(key, plan):
+  """plan = (tile, split_k) or None to drop the override (tools/tune_step_plans.py)."""
+  if plan is None:
+    _PLANS.pop(key, None)
+  else:
+    _PLANS[key] = (int(plan[0]), int(plan[1]))
+
+
+def gemm_plans():
+  return dict(_PLANS)
+
+
+def record_plan_keys(sink):
+  """While `sink` is a dict, every auto-planned ldm_gemm launch stores key -> (M, N, K, batch,
+  act, dtype) in it (tools/tune_step_plans.py enumerates a step's problems this way)."""
+  global _PLAN_RECORD
+  _PLAN_RECORD = sink
+
+
+def plan_candidates(M, N, K, batch, act, dtype):
+  """(tile, split_k) pairs worth timing for one problem."""
+  ktiles = K // (64 if dtype == BF16 else 32)
+  out = []
+  for tile, (bm, bn, res) in _TILE_DIMS.items():
+    if act == ACT_GEGLU and tile > 2:
+      continue
+    if tile >= 6 and N % bn != 0:
+      continue
+    tiles = -(-M // bm) * -(-N // bn) * batch
+    out.append((tile, 1))
+    if batch == 1 and tiles < 256 * res:         # sub-round launches: split-K candidates
+      out += [(tile, s) for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24)
+              if ktiles // s >= 4 and tiles * s <= 512 * res]
+  return out
+
+
+def _load_default_plans():
+  if os.environ.get("LDM_NO_PLANS") is not None:
+    return
+  d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans")
+  if os.path.isdir(d):
+    for name in sorted(os.listdir(d)):
+      if name.endswith(".json"):
+        load_plans(os.path.join(d, name))
+  extra = os.environ.get("LDM_GEMM_PLANS")
+  if extra:
+    load_plans(extra)
+
+
+_load_default_plans()
+
+
 def _gemm(p: GemmParams, device):
   if _GEMM_SKIP is not None:
     _GEMM_SKIP[0] += 1
@@ -110,6 +193,13 @@ def _gemm(p: GemmParams, device):
   ws = workspace(device)
   p.workspace = ws.data_ptr()
   p.workspace_bytes = ws.numel()
+  if p.tile == 0 and p.split_k == 0 and not p.a_scale and not p.ln_out and (_PLANS or _PLAN_RECORD is not None):
+    key = plan_key(p)
+    if _PLAN_RECORD is not None:
+      _PLAN_RECORD[key] = (p.M, p.N, p.K, p.batch, p.act, p.dtype)
+    plan = _PLANS.get(key)
+    if plan is not None:
+      p.tile, p.split_k = plan
   if _GEMM_TIMER is None:
     check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
     return

@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""In-situ plan tuner: for every distinct ldm_gemm problem of a captured U-Net step, try the
+candidate (tile, split_k) pairs ONE problem at a time and keep a candidate only if the WHOLE
+step (HIP graph, 10 replays, HIP events) gets faster.  Weights are cold, activations warm and
+neighbouring kernels present exactly as in the sampling loop -- unlike an isolated micro-
+benchmark.  Writes {key: [tile, split_k]} for ldm_tf2_amd/plans/.
+
+    python tools/tune_step_plans.py --out gpurun_out/plans.json [--batch 16] [--latent 32] [--dtype bf16]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as BN  # noqa: E402
+from ldm_tf2_amd import ops  # noqa: E402
+from ldm_tf2_amd import weights as Wt  # noqa: E402
+from ldm_tf2_amd.autoencoder import AutoencoderKL  # noqa: E402
+from ldm_tf2_amd.model_runners import LatentDiffusionModelSampler  # noqa: E402
+from ldm_tf2_amd.transformer import TransformerModel  # noqa: E402
+from ldm_tf2_amd.unet import UNet  # noqa: E402
+
+
+def main():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--batch", type=int, default=16)
+  ap.add_argument("--latent", type=int, default=32)
+  ap.add_argument("--dtype", default="bf16")
+  ap.add_argument("--out", default="gpurun_out/plans.json")
+  ap.add_argument("--budget-s", type=float, default=420.0)
+  ap.add_argument("--min-gain-us", type=float, default=4.0)
+  args = ap.parse_args()
+  dev = torch.device("cuda:0")
+  dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+  cfg = BN.FULL
+  for k in list(ops.gemm_plans()):
+    ops.set_plan(k, None)
+  w = {"unet": Wt.init_weights(Wt.unet_manifest(**cfg["unet"]), seed=2, scope="unet"),
+       "cond_stage_model": Wt.init_weights(Wt.transformer_manifest(**cfg["cond_stage_model"]), seed=2,
+                                           scope="cond_stage_model"),
+       "autoencoder": Wt.init_weights(Wt.decoder_manifest(**cfg["autoencoder_kl"]), seed=2, scope="autoencoder")}
+  unet = UNet(**cfg["unet"], weights=w["unet"], dtype=dt, device=dev)
+  txt = TransformerModel(**cfg["cond_stage_model"], weights=w["cond_stage_model"], dtype=dt, device=dev)
+  ae = AutoencoderKL(**cfg["autoencoder_kl"], weights=w["autoencoder"], dtype=dt, device=dev)
+  s = LatentDiffusionModelSampler(unet, ae, txt, use_graph=True, verbose=False, **dict(cfg["ldm"], num_ddim_steps=10))
+  B = args.batch
+  s.ddim_p_sample_loop(BN.synthetic_token_ids(B), [B, args.latent, args.latent, 4], guidance_scale=5., seed=0)
+  torch.cuda.synchronize()
+
+  keys = {}
+  ops.record_plan_keys(keys)
+  s._index_dev.fill_(9)
+  s._step(5.0, False, None, dec_index=False)
+  torch.cuda.synchronize()
+  ops.record_plan_keys(None)
+  print(f"{len(keys)} distinct ldm_gemm problems in one U-Net step", flush=True)
+
+  def step_ms(reps=10):
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+      s._step(5.0, False, None, dec_index=False)
+    for _ in range(3):
+      g.replay()
+    best = 1e9
+    for _ in range(2):
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(reps):
+        g.replay()
+      e1.record()
+      e1.synchronize()
+      best = min(best, e0.elapsed_time(e1) / reps)
+    return best
+
+  base = step_ms()
+  print(f"baseline step: {base:.3f} ms", flush=True)
+  t_start = time.time()
+  plans, cur = {}, base
+  # biggest problems first (they carry the most time)
+  order = sorted(keys.items(), key=lambda kv: -(kv[1][0] * kv[1][1] * kv[1][2] * kv[1][3]))
+  for key, (M, N, K, batch, act, dtype) in order:
+    if time.time() - t_start > args.budget_s:
+      print("time budget reached", flush=True)
+      break
+    best_c, best_ms = None, cur
+    for cand in ops.plan_candidates(M, N, K, batch, act, dtype):
+      ops.set_plan(key, cand)
+      try:
+        ms = step_ms()
+      except Exception as e:      # a candidate the library rejects (workspace, ...)
+        print("  ", key, cand, "rejected:", str(e)[:80], flush=True)
+        continue
+      if ms < best_ms - args.min_gain_us * 1e-3:
+        best_c, best_ms = cand, ms
+    ops.set_plan(key, best_c)
+    if best_c is not None:
+      plans[key] = list(best_c)
+      print(f"{key}: {best_c}  step {cur:.3f} -> {best_ms:.3f} ms", flush=True)
+      cur = best_ms
+  final = step_ms()
+  print(f"tuned step: {final:.3f} ms (baseline {base:.3f})", flush=True)
+  os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+  json.dump({"about": f"tools/tune_step_plans.py on MI355X, B={B}, latent {args.latent}, {args.dtype}: "
+                      f"step {base:.3f} -> {final:.3f} ms", "plans": plans}, open(args.out, "w"), indent=1)
+  print("wrote", args.out, flush=True)
+
+
+if __name__ == "__main__":
+  main()
