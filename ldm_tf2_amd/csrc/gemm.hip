@@ -20,8 +20,9 @@
 //     wave-instruction writes 64 x 16 B linearly, so the XOR swizzle is applied
 //     to the SOURCE chunk each lane fetches.  Two LDS stages form a ring: tile
 //     t+1 is issued while tile t is multiplied; s_waitcnt vmcnt(0) plus ONE raw
-//     s_barrier per K-tile orders it.  (A 3-stage ring with counted vmcnt was
-//     measured slower: one more stage costs a resident workgroup per CU.)
+//     s_barrier per K-tile orders it.  The 256x128 tile (one workgroup per CU
+//     either way) runs a 3-stage ring with a counted vmcnt instead; on the
+//     smaller tiles a third stage would cost a resident workgroup per CU.
 //   * the epilogue goes through LDS: accumulators are dropped as an f32 tile and
 //     re-read row-wise so that bias / addend / residual / output all move as
 //     16-byte vectors (the MFMA accumulator layout alone would give 2-byte
