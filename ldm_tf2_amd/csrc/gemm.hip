@@ -741,7 +741,8 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
       // calibration (tools/splitk_sweep.py): when the 256x128 tiling cannot fill the chip once
       // (small-M convolutions: 4x4 / 8x8 / 16x16 maps), two co-resident 128x128 workgroups per
       // CU measure 5-14 % faster than one 256x128 at the same split
-      if (c == 2 && (double)cdiv(p->M, 256) * cdiv(p->N, 128) * p->batch < 256.0) us *= 0.9;
+      static const bool no_t2pref = getenv("LDM_GEMM_NO_T2PREF") != nullptr;   // A/B switch
+      if (!no_t2pref && c == 2 && (double)cdiv(p->M, 256) * cdiv(p->N, 128) * p->batch < 256.0) us *= 0.9;
       if (split > 1) us += 3.0 + (double)p->M * p->N * 4.0 * (split + 1) / 3.0e6;   // bytes / (3 TB/s) in us
       if (us < best) { best = us; best_cfg = c; best_split = split; }
     }
