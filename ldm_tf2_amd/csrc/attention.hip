@@ -66,7 +66,10 @@ template <> struct AttnTraits<float> {
 // multiple of 32 the last tile's upper rows read unstaged LDS: they only ever feed output
 // rows >= SP, which are never stored.
 template <typename T, int SP, int KT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnArgs p) {
+// Waves per SIMD: the softmax (VALU, exp2) and the two MFMA phases of different waves overlap,
+// so residency pays: measured 130 -> 109 -> 91 us at T = 1024, Sp = 48 for 2 -> 3 -> 4 waves per
+// SIMD (5 spills 144 bytes per lane and loses again); the wide heads keep the compiler's choice.
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4 : 1) : 1)) void attn_kernel(AttnArgs p) {
   using TR = AttnTraits<T>;
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int NPC = TR::NPC;
