@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ x, 
 // C therefore packs several rows into a wave instead of idling most of its lanes, and
 // every lane has all its loads in flight at once.
 template <typename T, int LPR>
-__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, int64_t ldx,
+__global__ __launch_bounds__(256, 4) void layernorm_kernel(const T* __restrict__ x, int64_t ldx,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         T* __restrict__ out, int64_t ldo, int rows,
