@@ -83,6 +83,15 @@ def cpu_baseline(weights, latent, n_ddim):
     cores = os.cpu_count() or 1
   cores = max(1, min(cores, int(os.environ.get("LDM_CPU_BASELINE_THREADS", "16"))))
   torch.set_num_threads(cores)
+  cpu_model = "unknown CPU"
+  try:
+    with open("/proc/cpuinfo") as f:
+      for line in f:
+        if line.startswith("model name"):
+          cpu_model = line.split(":", 1)[1].strip()
+          break
+  except OSError:
+    pass
   g = np.random.default_rng(0)
   ids = synthetic_token_ids(1)
   x = g.standard_normal((2, latent, latent, 4)).astype(np.float32)
@@ -97,7 +106,7 @@ def cpu_baseline(weights, latent, n_ddim):
       t_unet = t_text * (2 * GF_UNET_ROW[latent]) / gf_text
       t_dec = t_text * GF_DECODE[latent] / gf_text
       per_image = n_ddim * t_unet + t_dec + t_text
-      return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+      return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
               "sample": (f"torch-CPU f32 oracle, {cores} threads: text-encode 2 rows = {t_text:.1f}s measured; "
                          "U-Net and decode legs extrapolated by FLOP ratio (host too slow to run them "
                          "inside the bounded sample)"),
@@ -112,7 +121,7 @@ def cpu_baseline(weights, latent, n_ddim):
     log(0, f"cpu oracle: decode {t_dec:.1f}s")
   per_image = n_ddim * t_unet + t_dec + t_text
   return {
-      "value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+      "value": 1.0 / per_image, "unit": "images/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
       "sample": (f"torch-CPU f32 oracle, {cores} threads: 1 U-Net eval of one image's CFG pair "
                  f"[2,{latent},{latent},4] = {t_unet:.2f}s, text-encode 2 rows = {t_text:.2f}s, "
                  f"KL decode 1 image = {t_dec:.2f}s; images/s = 1/({n_ddim}*unet + decode + text)"),
