@@ -123,6 +123,16 @@ typedef struct {
   const float* ln_beta;
   int64_t ld_ln;
   float ln_eps;
+  /* Second, TRANSPOSED output for the columns n >= n_split (the self-attention q|k|v projection
+   * in one launch: q|k row-major into `out`, v straight into the V^T layout the attention kernel
+   * reads, unet.py:270-276): element (m, n) goes to
+   *   out2 + (m / rows2) * stride2 + (n - n_split) * ld2 + (m % rows2)      (dtype of out).
+   * n_split must be a multiple of 160 and 128 or the forced tile's width (every tile then lies on
+   * one side), rows2 a multiple of 4; plain rows, batch 1, no split-K, no residual on that part.
+   * NULL = off. */
+  void* out2;
+  int64_t ld2, stride2;
+  int32_t n_split, rows2;
 } ldm_gemm_params;
 
 int ldm_gemm(const ldm_gemm_params* p, void* stream);

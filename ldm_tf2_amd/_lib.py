@@ -33,6 +33,7 @@ class GemmParams(C.Structure):
       ("tile", c_i32), ("alpha", c_f32),
       ("a_scale", c_vp), ("a_shift", c_vp), ("a_silu", c_i32), ("no_lead_pad", c_i32),
       ("ln_out", c_vp), ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ld_ln", c_i64), ("ln_eps", c_f32),
+      ("out2", c_vp), ("ld2", c_i64), ("stride2", c_i64), ("n_split", c_i32), ("rows2", c_i32),
   ]
 
 

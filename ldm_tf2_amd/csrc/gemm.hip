@@ -63,6 +63,9 @@ struct GemmArgs {
   const float* ln_beta;
   int64_t ld_ln;
   float ln_eps;
+  char* out2;                // transposed second output for the columns >= n_split (q|k|v in one launch)
+  int64_t ld2, stride2;
+  int n_split, rows2;
 };
 
 constexpr int kLnTile = 8;   // the tile whose BN (320) holds a whole row of the N = 320 layers
@@ -327,6 +330,35 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // ---- epilogue ---------------------------------------------------------------
   const int mb = m0 + wm * WTM + 4 * lh;
   const int nb = n0 + wn * WTN + lr;
+  if (p.out2 && n0 >= p.n_split) {
+    // this tile lies in the transposed part: 4 consecutive rows of one sample are contiguous
+    // in out2 (rows2 % 4 == 0, so a 4-row group never straddles two samples)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nb + j * 32;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int m = mb + i * 32 + 8 * r4;
+          if (m >= p.M) continue;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = apply_act(p.act, epi_pre(p, min(m + e, p.M - 1), n, acc[i][j][r4 * 4 + e]));
+          const int64_t off = (int64_t)(m / p.rows2) * p.stride2 + (int64_t)(n - p.n_split) * p.ld2 + (m % p.rows2);
+          if (p.out_dtype == LDM_BF16) {
+            u32x2 pk; pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
+            *(u32x2*)((bf16_t*)p.out2 + off) = pk;
+          } else {
+            f32x4 pk = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)((float*)p.out2 + off) = pk;
+          }
+        }
+      }
+    return;
+  }
   if (p.split_k > 1) {
     float* ws = p.ws + (int64_t)split * p.M * p.N;
 #pragma unroll
@@ -352,7 +384,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int PCOLS = BN / 8;                 // pieces per tile row (plain)
     const int pcols = geglu ? PCOLS / 2 : PCOLS;
     const int npieces = EROWS * pcols;
-    const int nout = geglu ? p.N / 2 : p.N;
+    const int nout = geglu ? p.N / 2 : (p.out2 ? p.n_split : p.N);
 #pragma unroll
    for (int ep = 0; ep < ESPLIT; ++ep) {
     if (ep > 0) __syncthreads();                  // previous pass fully read
@@ -725,6 +757,7 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
     if (p->tile > 0 && p->tile < kNumTiles && c != p->tile) continue;
     if (c == 5 && p->tile != 5) continue;   // experimental: only when forced
     if (c >= 6 && p->tile != c && (p->N % kTiles[c].bn != 0 || no160)) continue;   // 160/320-column tiles: N = 160*k layers
+    if (p->out2 && p->n_split % kTiles[c].bn != 0) continue;                        // every tile on one side of n_split
     if (geglu && c > 2 && c != 5) continue;
     const TileCfg t = kTiles[c];
     const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
@@ -840,6 +873,15 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     cfg = kLnTile;
     split = 1;
   }
+  if (p->out2) {
+    LDM_CHECK_ARG(!p->conv && p->batch == 1 && p->act != LDM_ACT_GEGLU && p->ldc_n == 1 && !p->ln_out && !p->residual,
+                  "ldm_gemm: out2 needs plain rows, batch 1, a row-major first output, no GEGLU / ln_out");
+    LDM_CHECK_ARG(p->n_split > 0 && p->n_split < p->N && p->n_split % kTiles[cfg].bn == 0,
+                  "ldm_gemm: n_split=%d must be a multiple of the tile width %d", p->n_split, kTiles[cfg].bn);
+    LDM_CHECK_ARG(p->rows2 > 0 && p->rows2 % 4 == 0 && p->M % p->rows2 == 0 && p->ld2 % 4 == 0 && p->stride2 % 4 == 0 &&
+                      ((uintptr_t)p->out2 % 16) == 0, "ldm_gemm: out2 geometry (rows2 %% 4, M %% rows2, ld2 / stride2 %% 4, alignment)");
+    split = 1;
+  }
   if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5, "ldm_gemm: GEGLU needs tile 1, 2 or 5");
   GemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -855,6 +897,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   a.alpha = p->alpha;
   a.ln_out = (char*)p->ln_out; a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_beta; a.ld_ln = p->ld_ln;
   a.ln_eps = p->ln_eps;
+  a.out2 = (char*)p->out2; a.ld2 = p->ld2; a.stride2 = p->stride2; a.n_split = p->n_split; a.rows2 = p->rows2;
   // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
   const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
   auto al = [](const void* q, int by) { return ((uintptr_t)q % by) == 0; };

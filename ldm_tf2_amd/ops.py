@@ -216,10 +216,13 @@ def linear_ln_supported(n_out, dtype):
 
 
 def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_rows=0,
-           alpha=1.0, tile=0, split_k=0, ln=None):
+           alpha=1.0, tile=0, split_k=0, ln=None, out2=None):
   """out[..., n] = act(alpha * x[..., :] . wt[n, :] + bias[n] + addend[group]) + residual.
   x [..., K]; wt [N, K] contiguous; out [..., N] (N/2 wide for GEGLU).
-  `ln=(gamma, beta, ln_out, eps)`: also writes ln_out = LayerNorm(out) (same shape/dtype)."""
+  `ln=(gamma, beta, ln_out, eps)`: also writes ln_out = LayerNorm(out) (same shape/dtype).
+  `out2` [G, N2, T']: the weight rows beyond out's width are a second projection whose result is
+  stored TRANSPOSED per group of T = M/G rows (q|k into `out`, v into the attention kernel's
+  V^T [rows, heads*Sp, T] in one launch)."""
   K = x.shape[-1]
   N = wt.shape[0]
   M = x.numel() // K
@@ -239,6 +242,11 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
     p.add_ld = addend.stride(0) if (addend.dim() == 2 and addend.shape[0] > 1) else 0
   p.act, p.dtype, p.out_dtype, p.alpha = act, code(x.dtype), code(out.dtype), alpha
   p.tile, p.split_k = tile, split_k
+  if out2 is not None:
+    assert out2.dtype == out.dtype and out2.dim() == 3 and out2.stride(2) == 1 and M % out2.shape[0] == 0
+    assert out.shape[-1] + out2.shape[1] == N and out2.shape[2] >= M // out2.shape[0]
+    p.out2, p.n_split, p.rows2 = _ptr(out2), out.shape[-1], M // out2.shape[0]
+    p.ld2, p.stride2 = out2.stride(1), out2.stride(0)
   if ln is not None:
     gamma, beta, ln_out, eps = ln
     assert ln_out.dtype == out.dtype and tuple(ln_out.shape) == tuple(out.shape)

@@ -69,6 +69,7 @@ class _ST:
     self.qk1 = torch.cat([L.split_kernel(w[a1 + "/query/kernel"], sp, dtype, dev),
                           L.split_kernel(w[a1 + "/key/kernel"], sp, dtype, dev)], 0).contiguous()
     self.v1 = L.split_kernel(w[a1 + "/value/kernel"], sp, dtype, dev)
+    self.qkv1 = torch.cat([self.qk1, self.v1], 0).contiguous()      # one launch: q | k | v (v stored as V^T)
     self.o1 = (L.merge_kernel(w[a1 + "/output/kernel"], sp, dtype, dev), L.vec(w[a1 + "/output/bias"], dev))
     self.q2 = L.split_kernel(w[a2 + "/query/kernel"], sp, dtype, dev)
     self.k2 = L.split_kernel(w[a2 + "/key/kernel"], sp, dtype, dev)
@@ -90,7 +91,7 @@ class UNet:
   def __init__(self, model_channels=320, out_channels=4, num_blocks=2,
                attention_resolutions=(4, 2, 1), dropout_rate=0.1, channel_mult=(1, 2, 4, 4),
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
-               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False):
+               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -102,6 +103,9 @@ class UNet:
     # step -- the whole-row 128x320 tile (one workgroup per CU) plus the extra epilogue pass cost
     # slightly more than the 15 LayerNorm launches they replace.  Opt-in (parity-tested).
     self._fuse_ln = bool(fuse_layernorm) or os.environ.get("LDM_FUSED_LN") is not None
+    # fuse_qkv: the self-attention q|k and v projections as one GEMM launch with a transposed second
+    # output (ldm_gemm out2); LDM_NO_FUSED_QKV=1 is the A/B switch
+    self._fuse_qkv = bool(fuse_qkv) and os.environ.get("LDM_NO_FUSED_QKV") is None
     self._fuse_cache = {}
     self._model_channels = model_channels
     self._out_channels = out_channels
@@ -250,10 +254,14 @@ class UNet:
     if not fuse_ln:
       ops.layernorm(ha, st.ln[0][0], st.ln[0][1], ln, LN_EPS)
     qk = B_.get("st_qk", (R, T, 2 * hs), dt)
-    ops.linear(ln, st.qk1, qk)
     tp = (T + 7) // 8 * 8
     vt = B_.get("st_vt", (R, hs, tp), dt, zero=True)
-    ops.bmm_nt(ln, st.v1, vt, transposed_out=True)
+    if self._fuse_qkv and T % 4 == 0:
+      # q | k | v in ONE launch: q|k row-major, v straight into the attention kernel's V^T layout
+      ops.linear(ln, st.qkv1, qk, out2=vt)
+    else:
+      ops.linear(ln, st.qk1, qk)
+      ops.bmm_nt(ln, st.v1, vt, transposed_out=True)
     att = B_.get("st_att", (R, T, hs), dt)
     ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale)
     hb = B_.get("st_b", (R, T, c), dt)

@@ -443,3 +443,30 @@ def test_linear_with_layernorm_output(dev, dtype, M, K):
   with pytest.raises(LdmHipError):                         # a tile cannot hold a 640-wide row: loud error
     o.linear(x.to(dev), rnd((640, K), dtype, 2).to(dev), torch.empty(M, 640, dtype=dtype, device=dev),
              ln=(torch.ones(640, device=dev), torch.zeros(640, device=dev), torch.empty(M, 640, dtype=dtype, device=dev), 1e-5))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("R,T,hs,K,tile", [(3, 64, 128, 128, 0), (2, 256, 640, 640, 0), (2, 1024, 384, 320, 0),
+                                          (2, 256, 640, 640, 6), (5, 16, 128, 192, 3)])
+def test_linear_with_transposed_second_output(dev, dtype, R, T, hs, K, tile):
+  """q|k|v in one launch: q|k row-major, v straight into the attention kernel's V^T [R, hs, T'] (ldm_gemm out2)."""
+  o = ops()
+  x = rnd((R, T, K), dtype, 1)
+  w = rnd((3 * hs, K), dtype, 2, K ** -0.5)
+  tp = (T + 7) // 8 * 8
+  qk = torch.full((R, T, 2 * hs), float("nan"), dtype=dtype, device=dev)
+  vt = torch.zeros(R, hs, tp, dtype=dtype, device=dev)
+  o.linear(x.to(dev), w.to(dev), qk, out2=vt, tile=tile)
+  torch.cuda.synchronize()
+  ref = x.float() @ w.float().t()
+  close(qk, ref[..., :2 * hs], dtype)
+  close(vt[..., :T], ref[..., 2 * hs:].transpose(1, 2), dtype)
+  assert vt[..., T:].float().abs().max().item() == 0 if tp > T else True
+  # identical to the two separate launches it replaces
+  qk2 = torch.empty_like(qk)
+  vt2 = torch.zeros_like(vt)
+  o.linear(x.to(dev), w[:2 * hs].contiguous().to(dev), qk2, tile=tile)
+  o.bmm_nt(x.to(dev), w[2 * hs:].contiguous().to(dev), vt2, transposed_out=True)
+  torch.cuda.synchronize()
+  assert (qk.float() - qk2.float()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2e-2)
+  assert (vt.float() - vt2.float()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2e-2)
