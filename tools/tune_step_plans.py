@@ -78,8 +78,11 @@ def main():
       best = min(best, e0.elapsed_time(e1) / reps)
     return best
 
-  for _ in range(3):                             # let clocks / caches settle: the first timings drift
-    base = step_ms()
+  base = step_ms()                               # let clocks settle: the first timings drift by 2-3 %
+  for _ in range(40):
+    prev, base = base, step_ms()
+    if abs(prev - base) < 0.002 * base:
+      break
   print(f"baseline step: {base:.3f} ms", flush=True)
   t_start = time.time()
   plans, cur = {k: list(v) for k, v in ops.gemm_plans().items() if k in keys}, base
