@@ -24,31 +24,41 @@ if "--json" in args:
 totals = {}
 for path in args:
   rows = list(csv.DictReader(open(path)))
-  evals = len({r["Dispatch_Id"] for r in rows if "time_embedding_kernel" in r["Kernel_Name"]})
   fam = collections.defaultdict(lambda: collections.defaultdict(float))
   dur = collections.defaultdict(float)
   cnt = collections.defaultdict(int)
-  seen = set()
-  # only dispatches INSIDE a U-Net evaluation count: from its time_embedding_kernel to its
-  # cfg_ddim_kernel (the text encoder's and the decoder's launches are left out)
+  # only dispatches INSIDE a complete U-Net evaluation count: from its time_embedding_kernel to
+  # its cfg_ddim_kernel, and only evaluations that contain the GEMM family (bench.py also
+  # replays a step captured WITHOUT it); the text encoder's and decoder's launches are left out
   rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-  inside = False
+  evals = 0
+  win = None
   for r in rows:
     n = r["Kernel_Name"]
     if "time_embedding_kernel" in n:
-      inside = True
-    if not inside:
+      win = {"fam": collections.defaultdict(lambda: collections.defaultdict(float)),
+             "dur": collections.defaultdict(float), "cnt": collections.defaultdict(int), "seen": set()}
+    if win is None:
       continue
     f = ("gemm_kernel" if "gemm_kernel<" in n else "attn_kernel" if "attn_kernel" in n else
          "groupnorm" if "gn_" in n else "layernorm" if "layernorm" in n else
          "splitk_reduce" if "splitk" in n else "other")
-    fam[f][r["Counter_Name"]] += float(r["Counter_Value"])
-    if r["Dispatch_Id"] not in seen:
-      seen.add(r["Dispatch_Id"])
-      dur[f] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-      cnt[f] += 1
+    win["fam"][f][r["Counter_Name"]] += float(r["Counter_Value"])
+    if r["Dispatch_Id"] not in win["seen"]:
+      win["seen"].add(r["Dispatch_Id"])
+      win["dur"][f] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+      win["cnt"][f] += 1
     if "cfg_ddim_kernel" in n:
-      inside = False
+      if win["cnt"].get("gemm_kernel", 0) > 0:
+        evals += 1
+        for f2, d in win["fam"].items():
+          for c, v in d.items():
+            fam[f2][c] += v
+        for f2, v in win["dur"].items():
+          dur[f2] += v
+        for f2, v in win["cnt"].items():
+          cnt[f2] += v
+      win = None
   print(f"{path}: {evals} U-Net evaluations")
   for f, d in fam.items():
     print(f"  {f:14s} {dur[f] / max(evals, 1):8.3f} ms/eval {cnt[f] / max(evals, 1):7.1f} launches/eval  " +
