@@ -31,7 +31,47 @@ EXTRA = [
 ]
 
 
+def oracle_pins():
+  """oracle_pins.json: outputs of the CPU oracle itself on small seeded problems (weights from
+  weights.init_weights, inputs from numpy default_rng: platform-independent).  Not reference
+  data -- the reference cannot run here -- but a pin of the checker: an accidental edit of
+  oracle/ldm_oracle.py that changes its arithmetic fails tests/test_oracle_pins.py."""
+  import numpy as np
+  from ldm_tf2_amd import weights as Wt
+  from oracle import ldm_oracle as O
+  ucfg = dict(model_channels=32, out_channels=4, num_blocks=1, channel_mult=(1, 2), num_heads=4)
+  tcfg = dict(vocab_size=100, encoder_stack_size=2, hidden_size=64, num_heads=4, size_per_head=16,
+              max_seq_len=16, filter_size=128)
+  kcfg = dict(latent_channels=4, channels=32, num_blocks=1, multipliers=(1, 2))
+  w = {"unet": Wt.init_weights(Wt.unet_manifest(context_dim=64, **ucfg), seed=7, mode="random", scope="unet"),
+       "cond_stage_model": Wt.init_weights(Wt.transformer_manifest(**tcfg), seed=7, mode="random",
+                                           scope="cond_stage_model"),
+       "autoencoder": Wt.init_weights(Wt.decoder_manifest(**kcfg), seed=7, mode="random", scope="autoencoder")}
+  g = np.random.default_rng(11)
+  x = g.standard_normal((2, 8, 8, 4)).astype(np.float32)
+  ids = g.integers(0, 100, size=(2, 16))
+  ctx = O.text_encoder(ids, w["cond_stage_model"], num_heads=4)
+  y = O.unet_forward(x, np.array([981, 21], dtype=np.int32), ctx, w["unet"], num_heads=4)
+  d = O.decoder_forward(x[:1], w["autoencoder"])
+  ldm = dict(num_steps=1000, beta_start=0.00085, beta_end=0.012, v_posterior=0., scale_factor=0.18215, eta=0.,
+             num_ddim_steps=10)
+  ids4 = np.concatenate([ids[:1], ids[:1], ids[1:], ids[1:]], 0)
+  img = O.ddim_p_sample_loop(ids4, x, w, ldm, guidance_scale=5., num_heads=4)
+  emb = O.get_time_embedding(np.array([981], dtype=np.int32), 320)
+  pin = lambda t: {"shape": list(t.shape), "l2": float(t.double().norm()), "mean": float(t.double().mean()),
+                   "head": [float(v) for v in t.flatten()[:8]]}
+  out = {"config": {"unet": ucfg, "text": tcfg, "kl": kcfg, "weights_seed": 7, "inputs_seed": 11},
+         "text_encoder": pin(ctx), "unet": pin(y), "decoder": pin(d), "ddim_loop_images": pin(img),
+         "time_embedding_t981_320": {"cos_0_3": [float(v) for v in emb[0, :3]],
+                                     "sin_0_3": [float(v) for v in emb[0, 160:163]]}}
+  json.dump(out, open(os.path.join(HERE, "oracle_pins.json"), "w"), indent=1)
+  return out
+
+
 def main():
+  if "--oracle-pins-only" in sys.argv:
+    oracle_pins()
+    return
   os.environ["HF_HUB_OFFLINE"] = "1"
   from transformers import BertTokenizerFast
   tok = BertTokenizerFast.from_pretrained("/root/reference/bert_model")
@@ -52,6 +92,7 @@ def main():
   g["alphas_cumprod_0"] = float(s["alphas_cumprod"][0])
   g["alphas_cumprod_981"] = float(s["alphas_cumprod"][981])
   json.dump(g, open(os.path.join(HERE, "schedule_kats.json"), "w"))
+  oracle_pins()
 
 
 if __name__ == "__main__":
