@@ -12,6 +12,81 @@ template <typename T> __device__ __forceinline__ void stf(T* p, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
 
+// ---- conv_in, LDS-resident weights: Cin = 4, Cout % 8 == 0, 9*Cin*Cout floats <= 64 KB --------
+// Persistent workgroups keep the whole HWIO kernel in LDS; a work item is (4 consecutive pixels
+// of a row, 8 consecutive couts): per input row 6 pixel loads (a 4-channel float pixel is one
+// 16-byte load) serve the 3 x 4 taps, every weight pair (2 ds_read_b128) is used for 4 pixels,
+// one 16-byte store per pixel.  Same accumulation order per output as the kernel below.
+template <typename TI, typename TO, int CIN>
+__global__ __launch_bounds__(256, 2) void conv_in_lds_kernel(const TI* __restrict__ x, int64_t ldx,
+                                                          const float* __restrict__ w,
+                                                          const float* __restrict__ bias,
+                                                          TO* __restrict__ out, int64_t ldo, int B, int H,
+                                                          int W, int Cout) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];      // [9*CIN][Cout]
+  const int nw = 9 * CIN * Cout;
+  for (int i = threadIdx.x * 4; i < nw; i += 256 * 4) *(f32x4*)(sw + i) = *(const f32x4*)(w + i);
+  __syncthreads();
+  const int c8n = Cout >> 3, wg4 = (W + 3) >> 2;
+  const int64_t total = (int64_t)B * H * wg4 * c8n;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(idx % c8n) * 8;
+    const int64_t g = idx / c8n;
+    const int ox0 = (int)(g % wg4) * 4, oy = (int)((g / wg4) % H), b = (int)(g / ((int64_t)wg4 * H));
+    float acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[j][e] = bias ? bias[c8 + e] : 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = oy + kh - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      float xr[6][CIN];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const int ix = ox0 + q - 1;
+        const bool ok = (unsigned)ix < (unsigned)W;
+        const TI* xp = x + ((int64_t)(b * H + iy) * W + (ok ? ix : 0)) * ldx;
+        if constexpr (CIN == 4 && sizeof(TI) == 4) {
+          const f32x4 v = *(const f32x4*)xp;
+#pragma unroll
+          for (int ci = 0; ci < 4; ++ci) xr[q][ci] = ok ? v[ci] : 0.f;
+        } else {
+#pragma unroll
+          for (int ci = 0; ci < CIN; ++ci) xr[q][ci] = ok ? ldf<TI>(xp + ci) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const float* wp = sw + (kh * 3 + kw) * CIN * Cout + c8;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci) {
+          const f32x4 w0 = *(const f32x4*)(wp + ci * Cout), w1 = *(const f32x4*)(wp + ci * Cout + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float xv = xr[j + kw][ci];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[j][e] += xv * w0[e]; acc[j][4 + e] += xv * w1[e]; }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (ox0 + j >= W) break;
+      TO* op = out + ((int64_t)(b * H + oy) * W + ox0 + j) * ldo + c8;
+      if constexpr (sizeof(TO) == 2) {
+        *(u32x4*)op = f32_to_chunk(acc[j], bf16_t());
+      } else {
+        f32x4 o0 = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]}, o1 = {acc[j][4], acc[j][5], acc[j][6], acc[j][7]};
+        *(f32x4*)op = o0;
+        *(f32x4*)(op + 4) = o1;
+      }
+    }
+  }
+}
+
 // ---- conv_in: Cin <= 8, any Cout.  thread = (pixel, 4 consecutive couts) -------
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void conv_small_in_kernel(const TI* __restrict__ x, int64_t ldx,
@@ -364,6 +439,23 @@ extern "C" int ldm_conv3x3_small(const void* x, int64_t ldx, int in_dtype, const
   LDM_CHECK_ARG(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "ldm_conv3x3_small: bad dims");
   hipStream_t s = (hipStream_t)stream;
   const int64_t npix = (int64_t)B * H * W;
+  if (Cin == 4 && Cout % 8 == 0 && (size_t)9 * Cin * Cout * sizeof(float) <= 64 * 1024 &&
+      ldo % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)kernel_hwio % 16) == 0 &&
+      (in_dtype != LDM_F32 || Cin != 4 || (ldx % 4 == 0 && ((uintptr_t)x % 16) == 0))) {
+    const size_t shm = (size_t)9 * Cin * Cout * sizeof(float);
+    dim3 g(grid_for(((npix + 3) / 4) * (Cout / 8), 256, 768));
+#define LAUNCH_INL(TI, TO, CI)                                                                     \
+  hipLaunchKernelGGL((conv_in_lds_kernel<TI, TO, CI>), g, dim3(256), shm, s, (const TI*)x, ldx,    \
+                     kernel_hwio, bias, (TO*)out, ldo, B, H, W, Cout)
+#define LAUNCH_INL_T(TI, TO) LAUNCH_INL(TI, TO, 4)   /* CIN = 3 spills in this form: it takes the kernel below */
+    if (in_dtype == LDM_F32 && out_dtype == LDM_F32) { LAUNCH_INL_T(float, float); }
+    else if (in_dtype == LDM_F32) { LAUNCH_INL_T(float, bf16_t); }
+    else if (out_dtype == LDM_F32) { LAUNCH_INL_T(bf16_t, float); }
+    else { LAUNCH_INL_T(bf16_t, bf16_t); }
+#undef LAUNCH_INL_T
+#undef LAUNCH_INL
+    return ldm_launch_status("ldm_conv3x3_small(in, lds)");
+  }
   if (Cin <= 8) {
     LDM_CHECK_ARG(Cout % 4 == 0, "ldm_conv3x3_small: Cout must be a multiple of 4 when Cin <= 8");
     dim3 g(grid_for(npix * (Cout / 4), 256, 8192));

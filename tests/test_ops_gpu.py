@@ -470,3 +470,20 @@ def test_linear_with_transposed_second_output(dev, dtype, R, T, hs, K, tile):
   torch.cuda.synchronize()
   assert (qk.float() - qk2.float()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2e-2)
   assert (vt.float() - vt2.float()).abs().max().item() <= (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 32, 32, 4, 320), (1, 9, 7, 3, 128), (2, 8, 8, 4, 12), (1, 16, 16, 4, 512)])
+def test_conv3x3_small_in_paths(dev, dtype, B, H, W, Cin, Cout):
+  """conv_in: LDS-resident-weights kernel (Cout % 8 == 0, kernel <= 64 KB) and the per-thread-weights
+  fallback (Cout = 12; Cout = 512 is 72 KB) against the oracle, writing into a channel slice."""
+  o = ops()
+  x = rnd((B, H, W, Cin), torch.float32, 1)
+  k = rnd((3, 3, Cin, Cout), torch.float32, 2, 0.3)
+  b = rnd((Cout,), torch.float32, 3)
+  wide = torch.full((B, H, W, Cout + 64), 7.0, dtype=dtype, device=dev)
+  out = wide[..., 64:]
+  o.conv3x3_small(x.to(dev), k.to(dev), b.to(dev), out)
+  torch.cuda.synchronize()
+  close(out, O.conv2d(x, k, b), dtype)
+  assert (wide[..., :64].float() == 7.0).all()
