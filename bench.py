@@ -164,8 +164,7 @@ def main():
   from ldm_tf2_amd.unet import UNet
 
   if args.no_plans:
-    for k in list(ops.gemm_plans()):
-      ops.set_plan(k, None)
+    ops.clear_plans()
   t_build = time.perf_counter()
   cfg = FULL
   w = {
@@ -223,14 +222,14 @@ def main():
   R = 2 * B
   sampler._index_dev.fill_(args.ddim_steps - 1)
 
+  from tools.gemm_hooks import skip_gemms, time_gemms
+
   def captured_step(skip_counter):
-    ops.set_gemm_skip(skip_counter)
-    try:
+    import contextlib
+    with (skip_gemms(skip_counter) if skip_counter is not None else contextlib.nullcontext()):
       g = torch.cuda.CUDAGraph()
       with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog thread may be live
         sampler._step(args.guidance, False, None, dec_index=False)
-    finally:
-      ops.set_gemm_skip(None)
     return g
 
   def replay_ms(g, reps=10):
@@ -255,11 +254,10 @@ def main():
     for _ in range(3):          # keep the GPU busy while the host enqueues the bracketed step
       sampler._graph.replay()
   sampler._index_dev.fill_(args.ddim_steps - 1)
-  ops.set_gemm_timer(timers)
-  sampler._step(args.guidance, False, None, dec_index=False)
-  torch.cuda.synchronize()
-  ops.set_gemm_timer(None)
-  bracket_ms = sum(x.elapsed_time(y) for x, y in timers)
+  with time_gemms(timers):
+    sampler._step(args.guidance, False, None, dec_index=False)
+    torch.cuda.synchronize()
+  bracket_ms = sum(rec[0].elapsed_time(rec[1]) for rec in timers)
   lat = args.latent
   gf_family = (GF_CONV_ROW.get(lat, 0) + GF_GEMM_ROW.get(lat, 0) - GF_CTX_KV_ROW) * R if lat in GF_CONV_ROW else None
   roofline = None
@@ -302,7 +300,7 @@ def main():
                    "latent": [lat, lat, 4], "parallelism": f"replicas x{world}, one all-gather of images"},
         "ms_per_unet_step": ms_unet_step,
         "unet_tflops": GF_UNET_ROW.get(lat, 0) * R / ms_unet_step if lat in GF_UNET_ROW else None,
-        "hip_graph": not args.no_graph, "gemm_plan_table_entries": len(ops.gemm_plans()),
+        "hip_graph": not args.no_graph, "gemm_plan_table_entries": len(ops.gemm_plans(2 * B, lat, args.dtype)),
         "roofline": roofline,
     }
     if keep_cpu:

@@ -21,6 +21,13 @@ from .weights import decoder_manifest, encoder_manifest, init_weights
 GROUP_NORM_EPS = 1e-6   # autoencoder.py:11
 
 
+def _chunk_rows(batch, sample_elems, dtype, max_chunk):
+  """Images per decoder / encoder pass: below ldm_gemm's 2 GiB operand limit and `max_chunk`."""
+  esize = 2 if dtype == torch.bfloat16 else 4
+  limit = max(1, ((1 << 31) - 4096) // (sample_elems * esize))
+  return max(1, min(batch, limit, max_chunk))
+
+
 class _Res:
   def __init__(self, w, p, dtype, dev):
     g = lambda n: w[p + "/" + n]
@@ -122,10 +129,42 @@ class _Decoder(_Blocks):
     self.gn_out = (L.vec(w["decoder/group_norm/gamma"], dev), L.vec(w["decoder/group_norm/beta"], dev))
     self.conv_out = (L.vec(w["decoder/conv_out/kernel"], dev), L.vec(w["decoder/conv_out/bias"], dev))
     self.buf = L.Buffers(dev)
+    self._ws = ops.new_workspace(dev)
+    self.max_chunk = 16
 
   def decode(self, latents, scale_factor=1.0, force_quantize=False):
-    """latents f32 [B,h,w,C]; computes Decoder(post_quant(quantize?(latents / scale_factor)))."""
+    """latents f32 [B,h,w,C]; computes Decoder(post_quant(quantize?(latents / scale_factor))).
+    Large batches run in chunks (samples are independent): no kernel operand may reach 2 GiB
+    (ldm_gemm addresses operands with 32-bit buffer offsets) and the scratch stays bounded
+    (`max_chunk` images at a time); the last chunk is the window ending at B, so every chunk
+    has the same shape and reuses the same scratch buffers."""
     assert latents.dtype == torch.float32 and latents.is_contiguous()
+    B, h, w, c = latents.shape
+    f = 2 ** sum(1 for blk in self.up if blk[0] == "up")
+    cout = self.conv_out[0].shape[-1]
+    out = torch.empty(B, f * h, f * w, cout, dtype=torch.float32, device=self.device)
+    n = _chunk_rows(B, self._max_sample_elems(h, w), self.dtype, self.max_chunk)
+    with ops.workspace_scope(self._ws):
+      for i in range(0, B, n):
+        i0 = min(i, B - n)
+        self._decode_chunk(latents[i0:i0 + n], scale_factor, force_quantize, out[i0:i0 + n])
+    return out
+
+  def _max_sample_elems(self, h, w):
+    """Largest activation of one sample, in elements (conv inputs / outputs and their GroupNorm
+    copies): channels x pixels at every level of the up path."""
+    ch = self.mid[0].cin
+    best = h * w * ch
+    for blk in self.up:
+      if blk[0] == "up":
+        h, w = 2 * h, 2 * w
+        ch = blk[1].shape[0]
+      else:
+        ch = max(blk[1].cin, blk[1].cout)
+      best = max(best, h * w * ch)
+    return best
+
+  def _decode_chunk(self, latents, scale_factor, force_quantize, out):
     B_, dt = self.buf, self.dtype
     B, h, w, c = latents.shape
     self._gnp = B_.get("gn_partial", (B * 128 * 32 * 2,), torch.float32)
@@ -164,8 +203,6 @@ class _Decoder(_Blocks):
           cur = self._attn(a, cur, self._dst(cur, (B, hh, ww, r.cout)))
     t0 = B_.get("gn", tuple(cur.shape), dt)
     ops.groupnorm(cur, self.gn_out[0], self.gn_out[1], t0, GROUP_NORM_EPS, silu=True, partial=self._gnp)
-    out = torch.empty(B, cur.shape[1], cur.shape[2], self.conv_out[0].shape[-1], dtype=torch.float32,
-                      device=self.device)
     ops.conv3x3_small(t0, self.conv_out[0], self.conv_out[1], out)
     return out
 
@@ -196,10 +233,30 @@ class _Encoder(_Blocks):
     self.quant = (L.vec(w["quant_conv/kernel"], dev), L.vec(w["quant_conv/bias"], dev))
     self.zc = w["quant_conv/kernel"].shape[0]
     self.buf = L.Buffers(dev)
+    self._ws = ops.new_workspace(dev)
+    self.max_chunk = 16
 
   def encode(self, images):
-    """images f32 [B,H,W,3] -> quant_conv(Encoder(images)) f32 [B,H/f,W/f,zc]."""
+    """images f32 [B,H,W,3] -> quant_conv(Encoder(images)) f32 [B,H/f,W/f,zc]; chunked over the
+    batch like `_Decoder.decode`."""
     assert images.dtype == torch.float32 and images.is_contiguous()
+    B, H, W, _ = images.shape
+    f = 2 ** sum(1 for blk in self.down if blk[0] == "down")
+    out = torch.empty(B, H // f, W // f, self.zc, dtype=torch.float32, device=self.device)
+    hh, ww, per = H, W, H * W * self.conv_in[0].shape[-1]
+    for blk in self.down:
+      if blk[0] == "down":
+        hh, ww = hh // 2, ww // 2
+      else:
+        per = max(per, hh * ww * max(blk[1].cin, blk[1].cout))
+    n = _chunk_rows(B, per, self.dtype, self.max_chunk)
+    with ops.workspace_scope(self._ws):
+      for i in range(0, B, n):
+        i0 = min(i, B - n)
+        self._encode_chunk(images[i0:i0 + n], out[i0:i0 + n])
+    return out
+
+  def _encode_chunk(self, images, out):
     B_, dt = self.buf, self.dtype
     B, H, W, _ = images.shape
     self._gnp = B_.get("gn_partial", (B * 128 * 32 * 2,), torch.float32)
@@ -224,7 +281,6 @@ class _Encoder(_Blocks):
     ops.groupnorm(cur, self.gn_out[0], self.gn_out[1], t0, GROUP_NORM_EPS, silu=True, partial=self._gnp)
     h = B_.get("enc_h", (B, shp[1], shp[2], self.zc), torch.float32)
     ops.conv3x3(t0, self.conv_out[0], h, bias=self.conv_out[1])
-    out = torch.empty(B, shp[1], shp[2], self.zc, dtype=torch.float32, device=self.device)
     ops.post_quant(h, 1.0, self.quant[0], self.quant[1], out)
     return out
 

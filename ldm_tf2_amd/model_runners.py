@@ -153,6 +153,20 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
       self._state_key = key
       self._graph = None
 
+  def _noise_table(self, noises, shape):
+    """Per-step noise in a buffer the sampler owns (one per shape): a captured graph reads it
+    at a fixed address, whatever tensor the caller passed."""
+    src = torch.as_tensor(np.asarray(noises) if not isinstance(noises, torch.Tensor) else noises,
+                          dtype=torch.float32)
+    assert tuple(src.shape) == tuple(shape), (tuple(src.shape), tuple(shape))
+    buf = getattr(self, "_noise_buf", None)
+    if buf is None or tuple(buf.shape) != tuple(shape):
+      buf = torch.empty(shape, dtype=torch.float32, device=self.device)
+      self._noise_buf = buf
+      self._graph = None
+    buf.copy_(src)
+    return buf
+
   def _step(self, guidance_scale, clip_denoised, noise_table, dec_index):
     """unet([xt; xt], t=steps[index]) -> CFG -> DDIM update, all on device."""
     self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps)
@@ -187,12 +201,13 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
     return sample
 
   def _set_context(self, cond):
-    cond = torch.as_tensor(cond).to(self.device)
-    key = (cond.data_ptr(), cond._version, tuple(cond.shape))
-    if getattr(self, "_ctx_key", None) != key:
-      self._unet.set_context(cond.contiguous())
-      self._ctx_key = key
-      self._graph = None
+    """Always re-projects the context (never cached on the tensor's address: the allocator
+    reuses a freed context's address for the next prompt).  The U-Net keeps the projections
+    in its own persistent buffers, one set per context shape, so a captured graph only has
+    to be rebuilt when that shape changes."""
+    cond = torch.as_tensor(cond).to(self.device).contiguous()
+    self._unet.set_context(cond)
+    self._ctx_shape = tuple(cond.shape)
 
   def ddim_p_sample_loop(self, cond_model_inputs, shape, guidance_scale=5., x_T=None,
                          noises=None, seed=0, first_sample_index=0, record=None):
@@ -217,15 +232,13 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
       if noises is None:
         noises = np.stack([normal_latents(seed + 1 + i, first_sample_index, B, (h, w, c))
                            for i in range(n)])
-      noise_table = torch.as_tensor(np.asarray(noises) if not isinstance(noises, torch.Tensor)
-                                    else noises, dtype=torch.float32).to(self.device).contiguous()
-      assert tuple(noise_table.shape) == (n, B, h, w, c)
+      noise_table = self._noise_table(noises, (n, B, h, w, c))
     self._xt.copy_(xt)
     self._x2[:B].copy_(xt)
     self._x2[B:].copy_(xt)
     self._index_dev.fill_(n - 1)                                          # :476
 
-    gkey = (float(guidance_scale), None if noise_table is None else noise_table.data_ptr())
+    gkey = (float(guidance_scale), noise_table is not None, self._ctx_shape)
     use_graph = self._use_graph and record is None
     t0 = torch.cuda.Event(enable_timing=True)
     t1 = torch.cuda.Event(enable_timing=True)
@@ -299,8 +312,7 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
       if noises is None:
         noises = np.stack([normal_latents(seed + 1 + i, first_sample_index, B, (h, w, c))
                            for i in range(n)])
-      noise_table = torch.as_tensor(np.asarray(noises) if not isinstance(noises, torch.Tensor)
-                                    else noises, dtype=torch.float32).to(self.device).contiguous()
+      noise_table = self._noise_table(noises, (n, B, h, w, c))
     self._xt.copy_(xt)
     self._x2[:B].copy_(xt)
     self._x2[B:].copy_(xt)
@@ -318,12 +330,13 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
       if r < num_records:                      # later (smaller) indices overwrite the slot
         sample_prog[:, r].copy_(self._xt)
         x0_prog[:, r].copy_(pred_x0)
-    images = self.decode_first_stage(self._xt).clone()
+    images = self.decode_first_stage(self._xt)
     flat = (B * num_records, h, w, c)
-    sp = self.decode_first_stage(sample_prog.reshape(flat).contiguous())
-    sp = sp.reshape(B, num_records, *sp.shape[1:]).clone()
-    xp = self.decode_first_stage(x0_prog.reshape(flat).contiguous())
-    xp = xp.reshape(B, num_records, *xp.shape[1:]).clone()
+    # the decoder chunks large batches itself (B * N // record_freq frames: 160 at B=4, N=200)
+    sp = self.decode_first_stage(sample_prog.reshape(flat))
+    sp = sp.reshape(B, num_records, *sp.shape[1:])
+    xp = self.decode_first_stage(x0_prog.reshape(flat))
+    xp = xp.reshape(B, num_records, *xp.shape[1:])
     return images, sp, xp
 
   def last_loop_ms_per_step(self):

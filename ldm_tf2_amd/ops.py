@@ -72,35 +72,41 @@ def row_ld(t) -> int:
 
 
 def workspace(device):
-  ws = _WS.get(device)
+  """Split-K partial-sum workspace for a launch made now.  ldm_gemm's slabs live from the GEMM
+  launch to its reduce launch, in stream order, so one workspace serves one stream at a time:
+  every model owns its own (`workspace_scope`, allocated at model build, before any graph
+  capture); launches outside a model use one per (device, current stream)."""
+  if _WS_SCOPE:
+    return _WS_SCOPE[-1]
+  key = (device, torch.cuda.current_stream(device).cuda_stream)
+  ws = _WS.get(key)
   if ws is None:
-    ws = torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
-    _WS[device] = ws
+    ws = new_workspace(device)
+    _WS[key] = ws
   return ws
 
 
-_GEMM_TIMER = None
+def new_workspace(device):
+  return torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
 
 
-def set_gemm_timer(sink):
-  """Measurement hook (bench.py): while `sink` is a list, every ldm_gemm launch is
-  bracketed by HIP events recorded on the launch stream and (start, end) is
-  appended to it.  None switches it off."""
-  global _GEMM_TIMER
-  _GEMM_TIMER = sink
+_WS_SCOPE = []
 
 
-_GEMM_SKIP = None
+class workspace_scope:
+  """`with workspace_scope(ws): ...` -- ldm_gemm launches inside use `ws` (a model's own
+  workspace), so two models replaying on different streams never share split-K slabs."""
 
+  def __init__(self, ws):
+    self._ws = ws
 
-def set_gemm_skip(counter):
-  """Measurement hook (bench.py): while `counter` is a one-element list, ldm_gemm launches are
-  NOT enqueued (only counted in counter[0]).  bench.py captures one U-Net step this way and
-  times it against the full step: the difference is the MFMA GEMM/conv family's share of a
-  step, measured with HIP events on graph replays (no per-launch event overhead).  Outputs of
-  such a step are garbage by construction; never set outside a measurement."""
-  global _GEMM_SKIP
-  _GEMM_SKIP = counter
+  def __enter__(self):
+    _WS_SCOPE.append(self._ws)
+    return self
+
+  def __exit__(self, *exc):
+    _WS_SCOPE.pop()
+    return False
 
 
 # ---- per-shape launch plans -----------------------------------------------------------------
@@ -108,11 +114,18 @@ def set_gemm_skip(counter):
 # the real step (weights cold in HBM, activations warm in L2/Infinity Cache, neighbours
 # competing) the optimum differs on some shapes, so measured overrides can be loaded:
 # {problem key: [tile, split_k]} JSON files written by tools/tune_step_plans.py, which times
-# WHOLE captured U-Net steps while varying one shape's plan at a time.  (Timing candidates
-# launch by launch in isolation was tried and made the step slower: 11.22 -> 11.44 ms.)
-# The packaged table plans/mi355x_txt2img_f8.json is loaded at import; LDM_NO_PLANS=1 disables
-# it, LDM_GEMM_PLANS=<file> adds another.  Plans only reorder float additions.
-_PLANS = {}
+# WHOLE captured U-Net steps while varying one shape's plan at a time.
+#
+# A table belongs to ONE step configuration (its file header: "config": {"rows": R, "latent":
+# h, "dtype": "bf16"|"f32"}) because a problem key names a shape, not the step it sits in: the
+# same shape occurs in different configurations with different in-situ optima.  Exactly one
+# table is active at a time; the U-Net activates the table of its (rows, latent, dtype) for the
+# duration of a forward (`plan_scope`), everything else runs on the cost model.  LDM_NO_PLANS=1
+# disables the packaged tables, LDM_GEMM_PLANS=<file> registers another.  Plans only reorder
+# float additions.
+_TABLES = {}          # (rows, latent, dtype code) -> {key: (tile, split_k)}
+_ACTIVE = {}          # the active table (possibly edited in place by tools/tune_step_plans.py)
+_ACTIVE_CFG = None
 _PLAN_RECORD = None
 _TILE_DIMS = {1: (256, 128, 1), 2: (128, 128, 2), 3: (128, 64, 3), 4: (64, 64, 5), 6: (128, 160, 2),
               7: (256, 160, 1), 8: (128, 320, 1)}       # BM, BN, resident workgroups per CU
@@ -123,27 +136,87 @@ def plan_key(p) -> str:
       p.M, p.N, p.K, p.batch, p.conv, p.H, p.W, p.stride, p.upsample, p.no_lead_pad, p.act, p.dtype, p.out_dtype)
 
 
+def _cfg_key(rows, latent, dtype):
+  dt = dtype if isinstance(dtype, int) else (BF16 if str(dtype) in ("bf16", "torch.bfloat16") else F32)
+  return (int(rows), int(latent), dt)
+
+
 def load_plans(path):
-  """Merge a {key: [tile, split_k]} JSON file into the plan table; returns the number of entries."""
+  """Registers the {key: [tile, split_k]} table of one JSON file under its header's
+  configuration; returns that configuration key.  Two files for one configuration that
+  disagree on a key are an error (a silently merged table is not the one that was measured)."""
   import json
   with open(path) as f:
     d = json.load(f)
-  d = d.get("plans", d)
-  for k, v in d.items():
-    _PLANS[k] = (int(v[0]), int(v[1]))
-  return len(d)
+  c = d.get("config")
+  if not c:
+    raise ValueError(f"{path}: plan table without a \"config\" header (rows / latent / dtype)")
+  ck = _cfg_key(c["rows"], c["latent"], c["dtype"])
+  table = _TABLES.setdefault(ck, {})
+  for k, v in d["plans"].items():
+    plan = (int(v[0]), int(v[1]))
+    if table.get(k, plan) != plan:
+      raise ValueError(f"{path}: plan for '{k}' conflicts with an already loaded table of config {ck}")
+    table[k] = plan
+  return ck
+
+
+def select_plans(rows=None, latent=None, dtype=None):
+  """Makes the table of one step configuration the active one (none when no table is
+  registered for it, or when called without arguments).  Returns the previous selection."""
+  global _ACTIVE, _ACTIVE_CFG
+  prev = _ACTIVE_CFG
+  ck = None if rows is None else _cfg_key(rows, latent, dtype)
+  _ACTIVE_CFG = ck
+  _ACTIVE = _TABLES.get(ck, {}) if ck is not None else {}
+  return prev
+
+
+class plan_scope:
+  """`with plan_scope(rows, latent, dtype): ...` -- the launches inside use that table."""
+
+  def __init__(self, rows, latent, dtype):
+    self._cfg = (rows, latent, dtype)
+
+  def __enter__(self):
+    self._prev = select_plans(*self._cfg)
+    return self
+
+  def __exit__(self, *exc):
+    if self._prev is None:
+      select_plans()
+    else:
+      select_plans(*self._prev)
+    return False
 
 
 def set_plan(key, plan):
-  """plan = (tile, split_k) or None to drop the override (tools/tune_step_plans.py)."""
+  """Edits the ACTIVE table: plan = (tile, split_k) or None to drop the override
+  (tools/tune_step_plans.py)."""
+  if _ACTIVE_CFG is None:
+    raise RuntimeError("set_plan: no configuration selected (select_plans first)")
+  table = _TABLES.setdefault(_ACTIVE_CFG, {})
   if plan is None:
-    _PLANS.pop(key, None)
+    table.pop(key, None)
   else:
-    _PLANS[key] = (int(plan[0]), int(plan[1]))
+    table[key] = (int(plan[0]), int(plan[1]))
+  select_plans(*_ACTIVE_CFG)
 
 
-def gemm_plans():
-  return dict(_PLANS)
+def gemm_plans(rows=None, latent=None, dtype=None):
+  """Copy of one configuration's table (the active one by default)."""
+  if rows is None:
+    return dict(_ACTIVE)
+  return dict(_TABLES.get(_cfg_key(rows, latent, dtype), {}))
+
+
+def plan_tables():
+  return {k: dict(v) for k, v in _TABLES.items()}
+
+
+def clear_plans():
+  _TABLES.clear()
+  select_plans()
 
 
 def record_plan_keys(sink):
@@ -186,28 +259,25 @@ def _load_default_plans():
 _load_default_plans()
 
 
-def _gemm(p: GemmParams, device):
-  if _GEMM_SKIP is not None:
-    _GEMM_SKIP[0] += 1
-    return
-  ws = workspace(device)
-  p.workspace = ws.data_ptr()
-  p.workspace_bytes = ws.numel()
-  if p.tile == 0 and p.split_k == 0 and not p.a_scale and not p.ln_out and (_PLANS or _PLAN_RECORD is not None):
+def resolve_plan(p: GemmParams):
+  """Applies the active plan table to an auto-planned problem (tile == 0 and split_k == 0)."""
+  if p.tile == 0 and p.split_k == 0 and not p.a_scale and not p.ln_out and (_ACTIVE or _PLAN_RECORD is not None):
     key = plan_key(p)
     if _PLAN_RECORD is not None:
       _PLAN_RECORD[key] = (p.M, p.N, p.K, p.batch, p.act, p.dtype)
-    plan = _PLANS.get(key)
+    plan = _ACTIVE.get(key)
     if plan is not None:
       p.tile, p.split_k = plan
-  if _GEMM_TIMER is None:
-    check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
-    return
-  e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-  e0.record()
+
+
+def _gemm(p: GemmParams, device):
+  """Every ldm_gemm launch of the package goes through here (tools/gemm_hooks.py wraps this
+  one function for measurements; the product path itself carries no hooks)."""
+  ws = workspace(device)
+  p.workspace = ws.data_ptr()
+  p.workspace_bytes = ws.numel()
+  resolve_plan(p)
   check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
-  e1.record()
-  _GEMM_TIMER.append((e0, e1))
 
 
 def linear_ln_supported(n_out, dtype):

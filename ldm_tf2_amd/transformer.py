@@ -61,9 +61,14 @@ class TransformerModel:
     self.tok = L.vec(weights["embedding"], dev)
     self.pos = L.vec(weights["positional_embedding"], dev)
     self.buf = L.Buffers(dev)
+    self._ws = ops.new_workspace(dev)
 
   def _encode(self, ids):
     """ids int64 device [R,T] -> [R,T,D] (transformer.py:257-272)."""
+    with ops.workspace_scope(self._ws):
+      return self._encode_rows(ids)
+
+  def _encode_rows(self, ids):
     B_, dt = self.buf, self.dtype
     R, T = ids.shape
     D, H, sp = self._hidden_size, self._num_heads, self.sp

@@ -123,8 +123,8 @@ class UNet:
     if missing:
       raise KeyError(f"UNet weights missing {len(missing)} tensors, e.g. {missing[:3]}")
     self.buf = L.Buffers(self.device)
+    self._ws = ops.new_workspace(self.device)   # this model's split-K workspace (ops.workspace_scope)
     self._compile(weights)
-    self._ctx_key = None
 
   # ---- build ---------------------------------------------------------------------
   def _compile(self, w):
@@ -188,19 +188,23 @@ class UNet:
   # ---- step-invariant cross-attention K / V ------------------------------------------
   def set_context(self, context):
     """Projects the text context through every cross-attention key/value layer once
-    (unet.py:274-275); valid until the next call with a different tensor."""
+    (unet.py:274-275).  The projections land in buffers owned by this model (one set per
+    context shape), so a captured step graph stays valid across calls; callers invoke this
+    EVERY time they are handed a context (32 small GEMMs) -- nothing is cached on tensor
+    identity, because a freed context's address is routinely reused by the next one."""
     if context.dtype != self.dtype:
       c2 = self.buf.get("ctx_cast", context.shape, self.dtype)
       ops.cast(context, c2)
       context = c2
     R, Tk, _ = context.shape
     tkp = (Tk + 7) // 8 * 8
-    for n, st in enumerate(self.sts):
-      hs = st.heads * st.sp
-      st.ctx_k = self.buf.get(f"ctxk{n}", (R, Tk, hs), self.dtype)
-      st.ctx_vt = self.buf.get(f"ctxv{n}", (R, hs, tkp), self.dtype, zero=True)
-      ops.linear(context, st.k2, st.ctx_k)
-      ops.bmm_nt(context, st.v2, st.ctx_vt, transposed_out=True)
+    with ops.workspace_scope(self._ws):
+      for n, st in enumerate(self.sts):
+        hs = st.heads * st.sp
+        st.ctx_k = self.buf.get(f"ctxk{n}", (R, Tk, hs), self.dtype)
+        st.ctx_vt = self.buf.get(f"ctxv{n}", (R, hs, tkp), self.dtype, zero=True)
+        ops.linear(context, st.k2, st.ctx_k)
+        ops.bmm_nt(context, st.v2, st.ctx_vt, transposed_out=True)
     self._ctx_rows = R
 
   # ---- blocks ------------------------------------------------------------------------------
@@ -287,6 +291,11 @@ class UNet:
     """x f32 [R,h,w,4].  Timestep either per row (`t_rows` int32 [R]) or, for the
     graph-replayed DDIM loop, `steps[*index]` for every row.  `shared_t=True` with
     t_rows declares that all rows carry t_rows[0]."""
+    # launch plans measured for this step configuration (ops.plan_scope), none otherwise
+    with ops.plan_scope(x.shape[0], x.shape[1], self.dtype), ops.workspace_scope(self._ws):
+      return self._forward(x, t_rows, steps, index, out, shared_t)
+
+  def _forward(self, x, t_rows, steps, index, out, shared_t):
     assert x.dtype == torch.float32 and x.is_contiguous()
     R, h, w, _ = x.shape
     nlev = max(self.skip_lvl)
@@ -370,9 +379,5 @@ class UNet:
     x = torch.as_tensor(inputs, dtype=torch.float32).to(self.device).contiguous()
     t = torch.as_tensor(time).to(torch.int32).to(self.device).contiguous()
     if context is not None:
-      ctx = torch.as_tensor(context).to(self.device)
-      key = (ctx.data_ptr(), ctx._version, tuple(ctx.shape))
-      if key != self._ctx_key:
-        self.set_context(ctx.contiguous())
-        self._ctx_key = key
+      self.set_context(torch.as_tensor(context).to(self.device).contiguous())
     return self.forward(x, t_rows=t)

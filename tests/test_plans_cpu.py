@@ -5,6 +5,9 @@ import glob
 import json
 import os
 
+import pytest
+import torch
+
 from ldm_tf2_amd import ops
 from ldm_tf2_amd._lib import GemmParams, lib
 
@@ -21,13 +24,57 @@ def test_key_and_table_roundtrip(tmp_path):
   p.stride = 1
   key = ops.plan_key(p)
   assert key == "M32768 N320 K2880 b1 conv1 H32 W32 s1 u0 nlp0 act0 dt%d odt%d" % (ops.BF16, ops.BF16)
-  before = ops.gemm_plans()
+  before = ops.plan_tables()
   f = tmp_path / "plans.json"
-  f.write_text(json.dumps({"about": "test", "plans": {key: [6, 1]}}))
-  assert ops.load_plans(str(f)) == 1
-  assert ops.gemm_plans()[key] == (6, 1)
-  ops.set_plan(key, None)
-  assert ops.gemm_plans() == before
+  f.write_text(json.dumps({"about": "test", "config": {"rows": 6, "latent": 24, "dtype": "bf16"},
+                           "plans": {key: [6, 1]}}))
+  try:
+    assert ops.load_plans(str(f)) == (6, 24, ops.BF16)
+    assert ops.gemm_plans(6, 24, "bf16")[key] == (6, 1)
+    assert ops.gemm_plans() == {}                      # nothing is active outside a scope
+    with ops.plan_scope(6, 24, torch.bfloat16):
+      assert ops.gemm_plans()[key] == (6, 1)
+      q = _params(32768, 320, 2880, conv=1)
+      q.H = q.W = 32
+      q.stride = 1
+      ops.resolve_plan(q)
+      assert (q.tile, q.split_k) == (6, 1)
+      with ops.plan_scope(6, 24, torch.float32):       # another configuration: its own (empty) table
+        assert ops.gemm_plans() == {}
+      assert ops.gemm_plans()[key] == (6, 1)
+      ops.set_plan(key, None)
+      assert key not in ops.gemm_plans()
+    assert ops.gemm_plans() == {}
+    # a second file for the same configuration must not silently override a measured plan
+    ops.load_plans(str(f))
+    g = tmp_path / "other.json"
+    g.write_text(json.dumps({"config": {"rows": 6, "latent": 24, "dtype": "bf16"}, "plans": {key: [1, 1]}}))
+    with pytest.raises(ValueError, match="conflicts"):
+      ops.load_plans(str(g))
+    h = tmp_path / "nohdr.json"
+    h.write_text(json.dumps({"plans": {key: [1, 1]}}))
+    with pytest.raises(ValueError, match="config"):
+      ops.load_plans(str(h))
+  finally:
+    ops.clear_plans()
+    ops._load_default_plans()
+  assert ops.plan_tables() == before
+
+
+def test_packaged_tables_one_per_configuration():
+  """Each packaged file names its step configuration, no two files share one, and the table the
+  U-Net activates for a configuration is exactly that file's (the C2 table used to be
+  overridden by the latent-64 one)."""
+  d = os.path.join(os.path.dirname(ops.__file__), "plans")
+  seen = {}
+  for path in sorted(glob.glob(os.path.join(d, "*.json"))):
+    j = json.load(open(path))
+    c = j["config"]
+    ck = (c["rows"], c["latent"], c["dtype"])
+    assert ck not in seen, f"{path} and {seen[ck]} both claim configuration {ck}"
+    seen[ck] = path
+    want = {k: tuple(v) for k, v in j["plans"].items()}
+    assert ops.gemm_plans(*ck) == want
 
 
 def test_candidates_respect_tile_rules():
