@@ -9,7 +9,9 @@ CXXFLAGS := --offload-arch=$(ARCH) -O3 -fPIC -std=c++17 -Wall -Wno-unused-functi
 
 all: $(OUT)
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/common.h include/ldm_hip.h
+HDRS  := $(wildcard $(CSRC)/*.h) include/ldm_hip.h
+
+build/%.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(CXXFLAGS) -c $< -o $@
 

@@ -366,6 +366,15 @@ class AutoencoderKL(_AutoencoderBase):
     x = torch.as_tensor(inputs, dtype=torch.float32).to(self.device).contiguous()
     return self._decoder.decode(x, scale_factor=scale_factor)
 
+  def call(self, inputs, sample_posterior=True, training=False, noise=None, seed=0):
+    """autoencoder.py:344-351: (decode(posterior.sample() | posterior.mode()), posterior).  The
+    sample's noise is an explicit input / seeded (the reference draws tf.random.normal)."""
+    posterior = self.encode(inputs, training=training)
+    latents = posterior.sample(noise=noise, seed=seed) if sample_posterior else posterior.mode()
+    return self.decode(latents, training=training), posterior
+
+  __call__ = call
+
 
 class AutoencoderVQ(_AutoencoderBase):
   """kwargs of autoencoder.py:371-383.  `latent_size` (build-only) is the spatial
@@ -409,3 +418,11 @@ class AutoencoderVQ(_AutoencoderBase):
     """autoencoder.py:430-436."""
     x = torch.as_tensor(latents, dtype=torch.float32).to(self.device).contiguous()
     return self._decoder.decode(x, scale_factor=scale_factor, force_quantize=force_quantize)
+
+  def call(self, inputs, return_indices=False, training=False):
+    """autoencoder.py:438-444: (reconstruction, codebook loss[, code indices])."""
+    quantized, loss, indices = self.encode(inputs, training=training)
+    outputs = self.decode(quantized, training=training)
+    return (outputs, loss, indices) if return_indices else (outputs, loss)
+
+  __call__ = call

@@ -461,14 +461,14 @@ static int halo_pick(const ldm_gemm_params* p, int cfg, HaloArgs* out_a, size_t*
 
 extern "C" int ldm_conv_prologue_supported(const ldm_gemm_params* p) {
   if (!p || !p->conv || p->stride != 1 || p->split_k > 1 || getenv("LDM_NO_HALO")) return 0;
-  if (!(p->tile == 0 || p->tile > 10)) return 0;
+  if (!(p->tile == 0 || p->tile > 20)) return 0;
   // plan WITH the prologue's LDS (scale/shift rows) so the answer matches the launch
   ldm_gemm_params q = *p;
   static const float dummy[4] __attribute__((aligned(16))) = {0, 0, 0, 0};
   if (!q.a_scale) { q.a_scale = dummy; q.a_shift = dummy; }
   HaloArgs a;
   size_t shm;
-  return halo_pick(&q, q.tile > 10 ? q.tile - 10 : 0, &a, &shm) > 0 ? 1 : 0;
+  return halo_pick(&q, q.tile > 20 ? q.tile - 20 : 0, &a, &shm) > 0 ? 1 : 0;
 }
 
 int ldm_conv_halo_try(const ldm_gemm_params* p, int cfg, void* stream) {

@@ -57,33 +57,50 @@ def _load_weights(path, what):
   return None
 
 
+def compvis_manifest_configs(config):
+  """Manifest kwargs of the three models as `build_from_config` will build them (what a CompVis
+  checkpoint must be mapped onto): U-Net with the text model's hidden size as context width, the
+  autoencoder section the sampler selects, for VQ with the run-time latent size and codebook."""
+  kind = config["ldm_sampling"]["autoencoder_type"]
+  unet_cfg = dict(config["unet"], context_dim=config["cond_stage_model"]["hidden_size"])
+  if kind == "kl":
+    ae_cfg = dict(config["autoencoder_kl"], attention_resolutions=())      # KL ignores it (autoencoder.py:339)
+  else:
+    ae_cfg = dict(config["autoencoder_vq"], latent_size=config["ldm_sampling"]["latent_shape"][1])
+  return dict(unet_cfg=unet_cfg, transformer_cfg=dict(config["cond_stage_model"]), autoencoder_cfg=ae_cfg)
+
+
 def build_from_config(config, dtype=torch.bfloat16, device="cuda:0", seed=2, use_graph=True,
                       verbose=True):
   ck = dict(config.get("pre_ckpt_paths", {}))
+  kind = config["ldm_sampling"]["autoencoder_type"]
+  if kind not in ("kl", "vq"):
+    raise NotImplementedError("invalid autoencoder type.")
+  latent_size = config["ldm_sampling"]["latent_shape"][1]
+  hidden = config["cond_stage_model"]["hidden_size"]
   if ck.get("compvis"):
     # one CompVis PyTorch checkpoint for all three models (checkpoint.py; what the
-    # reference reaches through convert_ckpt_pytorch_to_tf2.py + three TF checkpoints)
+    # reference reaches through convert_ckpt_pytorch_to_tf2.py + three TF checkpoints).  The
+    # sampling path decodes only: the checkpoint's encoder is not loaded (its layout differs
+    # between KL, double_z, and VQ); the U-Net's context width is the text model's hidden size;
+    # a VQ decoder's attention blocks depend on the latent size it will run at.
     from .checkpoint import from_compvis_state_dict
     sd = torch.load(ck["compvis"], map_location="cpu", weights_only=True)
     sd = {k: v.float().numpy() for k, v in sd.get("state_dict", sd).items() if torch.is_tensor(v)}
-    ae_key = "autoencoder_kl" if config["ldm_sampling"]["autoencoder_type"] == "kl" else "autoencoder_vq"
-    loaded = from_compvis_state_dict(sd, config["unet"], config["cond_stage_model"], config[ae_key])
+    loaded = from_compvis_state_dict(sd, **compvis_manifest_configs(config), with_encoder=False, kl=(kind == "kl"))
     _preloaded.update(loaded)
-  transformer =TransformerModel(**config["cond_stage_model"], dtype=dtype, device=device, seed=seed,
+  transformer = TransformerModel(**config["cond_stage_model"], dtype=dtype, device=device, seed=seed,
                                  weights=_load_weights(ck.get("cond_stage_model"), "cond_stage_model"))
   unet = UNet(**config["unet"], dtype=dtype, device=device, seed=seed,
-              context_dim=config["cond_stage_model"]["hidden_size"],
+              context_dim=hidden,
               weights=_load_weights(ck.get("unet"), "unet"))
-  kind = config["ldm_sampling"]["autoencoder_type"]
   if kind == "kl":
     autoencoder = AutoencoderKL(**config["autoencoder_kl"], dtype=dtype, device=device, seed=seed,
                                 weights=_load_weights(ck.get("autoencoder"), "autoencoder"))
   elif kind == "vq":
     autoencoder = AutoencoderVQ(**config["autoencoder_vq"], dtype=dtype, device=device, seed=seed,
-                                latent_size=config["ldm_sampling"]["latent_shape"][1],
+                                latent_size=latent_size,
                                 weights=_load_weights(ck.get("autoencoder"), "autoencoder"))
-  else:
-    raise NotImplementedError("invalid autoencoder type.")
   return LatentDiffusionModelSampler(unet=unet, autoencoder=autoencoder, cond_stage_model=transformer,
                                      use_graph=use_graph, verbose=verbose, **config["ldm"])
 

@@ -36,9 +36,11 @@ def close(got, ref, dtype, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (64, 192, 1280), (1024, 64, 64), (700, 640, 128)])
 def test_linear(dev, dtype, tile, M, N, K):
+  if tile >= 9 and dtype != torch.bfloat16:
+    pytest.skip("tiles 9-13 are the bf16 16x16x32 MFMA path")
   x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
   bias = rnd((N,), torch.float32, 3)
   res = rnd((M, N), dtype, 4)
@@ -68,6 +70,13 @@ def test_linear_act_splitk(dev, dtype, act):
     out = torch.zeros(M, nout, dtype=dtype, device=dev)
     o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), act=code, split_k=split)
     close(out, ref, dtype)
+  if dtype == torch.bfloat16:
+    # 16x16x32 MFMA tiles: every activation epilogue and the split-K slab layout
+    for tile in ((11, 12) if act == "geglu" else (9, 10, 11, 12, 13)):
+      for split in (1, 4):
+        out = torch.zeros(M, nout, dtype=dtype, device=dev)
+        o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), act=code, split_k=split, tile=tile)
+        close(out, ref, dtype)
 
 
 @pytest.mark.parametrize("dtype", DT)
@@ -106,7 +115,8 @@ def test_conv3x3(dev, dtype, cfg):
   res = rnd((B, OH, OW, Cout), dtype, 6)
   ref = ref + res.float()
   wt = k.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous().to(dev)
-  for tile in (0, 1, 2, 3, 4, 6, 7, 8, 11, 12, 13):     # 1-8 implicit GEMM tiles, 11-13 halo tiles
+  bf = (9, 10, 11, 12, 13) if dtype == torch.bfloat16 else ()     # 16x16x32 MFMA tiles: bf16 only
+  for tile in (0, 1, 2, 3, 4, 6, 7, 8) + bf + (21, 22, 23):     # 1-11 implicit GEMM tiles, 21-23 halo tiles
     out = torch.zeros(B, OH, OW, Cout, dtype=dtype, device=dev)
     o.conv3x3(x.to(dev), wt, out, bias=bias.to(dev), stride=cfg["stride"], upsample=cfg["up"],
               addend=addend.to(dev), residual=res.to(dev), tile=tile)
@@ -139,7 +149,7 @@ def test_conv3x3_groupnorm_prologue(dev, dtype, cfg):
   shift = torch.empty(B, Cin, device=dev)
   o.groupnorm_scale_shift(xd, gamma.to(dev), beta.to(dev), scale, shift, 1e-5)
   ran = 0
-  for tile in (11, 12, 13):
+  for tile in (21, 22, 23):
     out = torch.zeros(tuple(ref.shape), dtype=dtype, device=dev)
     if not o.conv3x3_prologue_supported(xd, wt, out, upsample=cfg["up"], tile=tile):
       continue
