@@ -204,7 +204,8 @@ def test_progressive_sampler_at_full_size_chunks_the_decode(dev):
   assert tuple(sp.shape) == (B, 40, 256, 256, 3) and tuple(xp.shape) == tuple(sp.shape)
   assert bool(torch.isfinite(sp).all()) and bool(torch.isfinite(xp).all())
   # slot r holds the sample after the step with index r (model_runners.py:545-553): slot 0 is the final x_0
-  assert rel(sp[:, 0], images.cpu()) < 1e-6
+  # (decoded in a 16-frame chunk vs the 4-image call: other GEMM tiles, i.e. bf16 rounding order)
+  assert rel(sp[:, 0], images.cpu()) < 2e-2
   # a chunked decode equals decoding the same frames on their own
   lat = torch.randn(37, 32, 32, 4, generator=torch.Generator().manual_seed(3))
   whole = ae.decode(lat, scale_factor=0.18215)
