@@ -57,6 +57,16 @@ FULL = dict(
 )
 
 
+# BASELINE.json configs -> (batch per GPU, latent, DDIM steps, U-Net dtype)
+CONFIGS = {
+    "c2": dict(batch_per_gpu=4, latent=32, ddim_steps=50, dtype="f32"),
+    "c3": dict(batch_per_gpu=16, latent=32, ddim_steps=200, dtype="bf16"),
+    "c4": dict(batch_per_gpu=8, latent=32, ddim_steps=200, dtype="bf16"),
+    "c5": dict(batch_per_gpu=4, latent=64, ddim_steps=200, dtype="f32"),
+    "c5bf16": dict(batch_per_gpu=4, latent=64, ddim_steps=200, dtype="bf16"),
+}
+
+
 def synthetic_token_ids(batch, seed=1, vocab=30522, T=77):
   """uncond rows = [CLS][SEP][PAD]...; cond rows = uniform random ids."""
   uncond = np.array([[101, 102] + [0] * (T - 2)], dtype=np.int64)
@@ -70,18 +80,19 @@ def log(rank, *a):
 
 
 def cpu_baseline(weights, latent, n_ddim):
-  """CPU oracle on a bounded sample: ONE U-Net evaluation of the CFG pair of one image
-  (2 rows), ONE text encoding of its 2 rows and ONE decode, extrapolated to
-  n_ddim U-Net evaluations per image.  Test infrastructure used as the checker's
-  clock only -- never part of the measured GPU path."""
+  """CPU oracle (a port of the reference arithmetic: TensorFlow is not installable) on a
+  BOUNDED sample: BASELINE configs[0] itself -- run_ldm_sampler's path at latent_shape
+  [1,32,32,4], num_ddim_steps=10, random-init full-size weights, fixed seed: text-encode 2 rows,
+  10 DDIM steps (one CFG U-Net evaluation each), KL decode -- run once, for real (~15-20 s).
+  images/s at the bench's step count = 1 / (n_ddim * measured seconds per DDIM step + text +
+  decode).  Threads = the cores this process may run on (affinity), all of them.  Test
+  infrastructure used as the checker's clock only -- never part of the measured GPU path."""
   from oracle import ldm_oracle as O
-  # threads = the cores this process may actually run on (a cgroup / affinity share of
-  # the host), not os.cpu_count(): oversubscribing the share makes torch-CPU crawl
   try:
-    cores = len(os.sched_getaffinity(0))
+    affinity = len(os.sched_getaffinity(0))
   except AttributeError:
-    cores = os.cpu_count() or 1
-  cores = max(1, min(cores, int(os.environ.get("LDM_CPU_BASELINE_THREADS", "16"))))
+    affinity = os.cpu_count() or 1
+  cores = max(1, int(os.environ.get("LDM_CPU_BASELINE_THREADS", affinity)))
   torch.set_num_threads(cores)
   cpu_model = "unknown CPU"
   try:
@@ -94,38 +105,42 @@ def cpu_baseline(weights, latent, n_ddim):
     pass
   g = np.random.default_rng(0)
   ids = synthetic_token_ids(1)
-  x = g.standard_normal((2, latent, latent, 4)).astype(np.float32)
+  x_T = g.standard_normal((1, latent, latent, 4)).astype(np.float32)
+  n_cpu = 10
+  ldm = dict(FULL["ldm"], num_ddim_steps=n_cpu)
+  sched = O.make_schedule(ldm["num_steps"], ldm["beta_start"], ldm["beta_end"], 0., n_cpu)
   with torch.no_grad():
     t0 = time.perf_counter()
     ctx = O.text_encoder(ids, weights["cond_stage_model"])
     t_text = time.perf_counter() - t0
-    log(0, f"cpu oracle: text encoder {t_text:.1f}s ({cores} threads)")
-    if t_text > 45.0:
-      # host too slow for the bounded sample: extrapolate the other two legs by FLOPs
-      gf_text = 2 * GF_TEXT_ROW
-      t_unet = t_text * (2 * GF_UNET_ROW[latent]) / gf_text
-      t_dec = t_text * GF_DECODE[latent] / gf_text
-      per_image = n_ddim * t_unet + t_dec + t_text
-      return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
-              "sample": (f"torch-CPU f32 oracle, {cores} threads: text-encode 2 rows = {t_text:.1f}s measured; "
-                         "U-Net and decode legs extrapolated by FLOP ratio (host too slow to run them "
-                         "inside the bounded sample)"),
-              "ms_per_unet_step": t_unet * 1e3}
+    log(0, f"cpu oracle: text encoder {t_text:.1f}s ({cores} threads, affinity {affinity})")
+    xt = torch.from_numpy(x_T)
     t0 = time.perf_counter()
-    O.unet_forward(x, np.array([981, 981], dtype=np.int32), ctx, weights["unet"])
-    t_unet = time.perf_counter() - t0
-    log(0, f"cpu oracle: U-Net eval {t_unet:.1f}s")
+    budget_hit = False
+    done = 0
+    for index in range(n_cpu - 1, -1, -1):
+      xt, _, _ = O.ddim_sample(xt, ctx, index, sched, weights["unet"], 5.0, None, clip_denoised=False)
+      done += 1
+      if time.perf_counter() - t0 > 60.0:       # slow host: stop early, still a measured per-step time
+        budget_hit = True
+        break
+    t_loop = time.perf_counter() - t0
+    t_step = t_loop / done
+    log(0, f"cpu oracle: {done} DDIM steps in {t_loop:.1f}s")
     t0 = time.perf_counter()
-    O.decoder_forward(torch.from_numpy(x[:1]), weights["autoencoder"])
+    O.decoder_forward(xt / ldm["scale_factor"], weights["autoencoder"])
     t_dec = time.perf_counter() - t0
     log(0, f"cpu oracle: decode {t_dec:.1f}s")
-  per_image = n_ddim * t_unet + t_dec + t_text
+  per_image = n_ddim * t_step + t_dec + t_text
+  c1_images_per_s = 1.0 / (n_cpu * t_step + t_dec + t_text)
   return {
-      "value": 1.0 / per_image, "unit": "images/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
-      "sample": (f"torch-CPU f32 oracle, {cores} threads: 1 U-Net eval of one image's CFG pair "
-                 f"[2,{latent},{latent},4] = {t_unet:.2f}s, text-encode 2 rows = {t_text:.2f}s, "
-                 f"KL decode 1 image = {t_dec:.2f}s; images/s = 1/({n_ddim}*unet + decode + text)"),
-      "ms_per_unet_step": t_unet * 1e3,
+      "value": 1.0 / per_image, "unit": "images/s", "cores": cores, "affinity_cores": affinity,
+      "cpu_model": cpu_model, "kind": "port",
+      "sample": (f"torch-CPU f32 oracle, {cores} threads: BASELINE configs[0] run once (latent [1,{latent},{latent},4], "
+                 f"{done}{' of 10 (60 s budget)' if budget_hit else ''} DDIM steps with CFG = {t_loop:.2f}s, text-encode 2 rows = "
+                 f"{t_text:.2f}s, KL decode = {t_dec:.2f}s => {c1_images_per_s:.4f} images/s at 10 steps); value = "
+                 f"1/({n_ddim} * {t_step:.3f}s + decode + text)"),
+      "ms_per_unet_step": t_step * 1e3, "c1_images_per_s_10_steps": c1_images_per_s,
   }
 
 
@@ -134,18 +149,29 @@ def main():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2)
   ap.add_argument("--warmup", type=int, default=1)
-  ap.add_argument("--batch-per-gpu", type=int, default=16)
-  ap.add_argument("--ddim-steps", type=int, default=200)
-  ap.add_argument("--latent", type=int, default=32)
-  ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS),
+                  help="BASELINE.json configuration: c3 = configs[2] (the one the metric is quoted on, default), "
+                       "c2 = configs[1], c4 = configs[3] (8 per GPU: the multi-GPU scaling point), c5 = configs[4]")
+  ap.add_argument("--batch-per-gpu", type=int, default=None)
+  ap.add_argument("--ddim-steps", type=int, default=None)
+  ap.add_argument("--latent", type=int, default=None)
+  ap.add_argument("--dtype", default=None, choices=["bf16", "f32"])
+  ap.add_argument("--decoder-dtype", default=None, choices=["bf16", "f32"],
+                  help="dtype of the text encoder + KL decoder (default: the U-Net's)")
   ap.add_argument("--guidance", type=float, default=5.0)
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-graph", action="store_true")
+  ap.add_argument("--no-variant", action="store_true",
+                  help="skip the extra pass with the text encoder / decoder in the other precision")
   ap.add_argument("--no-plans", action="store_true",
                   help="A/B: ldm_gemm's cost-model tile/split choice only (ignore the packaged in-situ plan table)")
   ap.add_argument("--fuse-gn", action="store_true",
                   help="A/B: GroupNorm+SiLU as the halo conv's prologue instead of a separate pass")
   args = ap.parse_args()
+  preset = CONFIGS[args.config]
+  for k, v in preset.items():
+    if getattr(args, k) is None:
+      setattr(args, k, v)
 
   from ldm_tf2_amd import distributed as D
   rank, world, local = D.init_from_env()
@@ -156,6 +182,8 @@ def main():
   torch.cuda.set_device(local)
   dev = torch.device("cuda", local)
   dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+  dec_name = args.decoder_dtype or args.dtype
+  dec_dtype = torch.bfloat16 if dec_name == "bf16" else torch.float32
 
   from ldm_tf2_amd import ops, weights as Wt
   from ldm_tf2_amd.autoencoder import AutoencoderKL
@@ -176,8 +204,8 @@ def main():
   }
   log(rank, f"weights generated in {time.perf_counter() - t_build:.1f}s")
   unet = UNet(**cfg["unet"], weights=w["unet"], dtype=dtype, device=dev, fuse_groupnorm=args.fuse_gn)
-  txt = TransformerModel(**cfg["cond_stage_model"], weights=w["cond_stage_model"], dtype=dtype, device=dev)
-  ae = AutoencoderKL(**cfg["autoencoder_kl"], weights=w["autoencoder"], dtype=dtype, device=dev)
+  txt = TransformerModel(**cfg["cond_stage_model"], weights=w["cond_stage_model"], dtype=dec_dtype, device=dev)
+  ae = AutoencoderKL(**cfg["autoencoder_kl"], weights=w["autoencoder"], dtype=dec_dtype, device=dev)
   ldm = dict(cfg["ldm"], num_ddim_steps=args.ddim_steps)
   sampler = LatentDiffusionModelSampler(unet, ae, txt, use_graph=not args.no_graph, verbose=False, **ldm)
   keep_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
@@ -190,10 +218,16 @@ def main():
   ids = synthetic_token_ids(B)
   first, _ = D.shard_range(rank, B)
 
-  def one_pass():
-    images = sampler.ddim_p_sample_loop(ids, shape, guidance_scale=args.guidance, seed=0,
-                                        first_sample_index=first)
-    return D.all_gather_images(images)
+  u8 = torch.empty(B, 8 * args.latent, 8 * args.latent, 3, dtype=torch.uint8, device=dev)
+  mm_scratch = torch.empty(B * 128, dtype=torch.float32, device=dev)
+
+  def one_pass(smp=None):
+    """text-encode -> N DDIM steps -> KL decode -> per-image min-max to uint8 (run_ldm_sampler.py:18-25)
+    -> ONE all-gather of the uint8 images (4x less payload than gathering float32)."""
+    images = (smp or sampler).ddim_p_sample_loop(ids, shape, guidance_scale=args.guidance, seed=0,
+                                                 first_sample_index=first)
+    ops.minmax_u8(images.contiguous(), u8, scratch=mm_scratch)
+    return D.all_gather_images(u8), images
 
   for _ in range(args.warmup):
     one_pass()
@@ -202,15 +236,35 @@ def main():
   t0 = time.perf_counter()
   loop_ms = []
   for _ in range(args.steps):
-    out = one_pass()
+    out, last_f32 = one_pass()
     loop_ms.append(sampler._loop_events)
   D.barrier()
   torch.cuda.synchronize()
   elapsed = time.perf_counter() - t0
   elapsed = D.max_over_ranks(elapsed, dev)
   ms_unet_step = float(np.mean([a.elapsed_time(b) / n for a, b, n in loop_ms]))
-  assert tuple(out.shape) == (world * B, 8 * args.latent, 8 * args.latent, 3)
-  assert bool(torch.isfinite(out).all()), "non-finite images"
+  assert tuple(out.shape) == (world * B, 8 * args.latent, 8 * args.latent, 3) and out.dtype == torch.uint8
+  assert bool(torch.isfinite(last_f32).all()), "non-finite images"
+  loop_ms_ranks = D.gather_floats(ms_unet_step, dev)
+  # the same pass with the text encoder + decoder in the OTHER precision, beside the headline
+  # (one warm-up + one timed pass; reported, never the headline)
+  other_name = "f32" if dec_name == "bf16" else "bf16"
+  other_dtype = torch.float32 if other_name == "f32" else torch.bfloat16
+  other_value = None
+  if world == 1 and not args.no_variant:
+    w2 = w if w is not None else {
+        "cond_stage_model": Wt.init_weights(Wt.transformer_manifest(**cfg["cond_stage_model"]), seed=2, scope="cond_stage_model"),
+        "autoencoder": Wt.init_weights(Wt.decoder_manifest(**cfg["autoencoder_kl"]), seed=2, scope="autoencoder")}
+    txt2 = TransformerModel(**cfg["cond_stage_model"], weights=w2["cond_stage_model"], dtype=other_dtype, device=dev)
+    ae2 = AutoencoderKL(**cfg["autoencoder_kl"], weights=w2["autoencoder"], dtype=other_dtype, device=dev)
+    s2 = LatentDiffusionModelSampler(unet, ae2, txt2, use_graph=not args.no_graph, verbose=False, **ldm)
+    one_pass(s2)
+    torch.cuda.synchronize()
+    tv = time.perf_counter()
+    one_pass(s2)
+    torch.cuda.synchronize()
+    other_value = B / (time.perf_counter() - tv)
+    del s2, txt2, ae2
 
   # ---- the MFMA GEMM/conv family's share of a step -------------------------------------
   # Two captured HIP graphs of the SAME step, one with every ldm_gemm launch left out
@@ -294,10 +348,14 @@ def main():
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": (f"txt2img-f8 1.45B LDM ({which}): B={B}/GPU, latent {lat}x{lat}x4, "
-                                f"{args.ddim_steps} DDIM steps, CFG {args.guidance:g}, {args.dtype} U-Net/text/decoder, "
-                                "f32 scheduler, random-init weights, synthetic x_T + random BERT ids"),
+                                f"{args.ddim_steps} DDIM steps, CFG {args.guidance:g}, {args.dtype} U-Net, {dec_name} text "
+                                "encoder + KL decoder, f32 scheduler, random-init weights, synthetic x_T + random BERT ids"),
                    "batch_per_gpu": B, "global_batch": world * B, "ddim_steps": args.ddim_steps,
-                   "latent": [lat, lat, 4], "parallelism": f"replicas x{world}, one all-gather of images"},
+                   "latent": [lat, lat, 4],
+                   "parallelism": f"replicas x{world}, one all-gather of the uint8 images ({B * 64 * lat * lat * 3} B per rank)"},
+        "world_size": D.world_size(), "backend": D.backend_name(),
+        "ms_per_unet_step_per_rank": loop_ms_ranks,
+        f"value_with_{other_name}_text_and_decoder": other_value,
         "ms_per_unet_step": ms_unet_step,
         "unet_tflops": GF_UNET_ROW.get(lat, 0) * R / ms_unet_step if lat in GF_UNET_ROW else None,
         "hip_graph": not args.no_graph, "gemm_plan_table_entries": len(ops.gemm_plans(2 * B, lat, args.dtype)),

@@ -149,13 +149,14 @@ __global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(GemmArgs p) {
 
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
-constexpr int kNumTiles = 14;
+constexpr int kNumTiles = 13;
 constexpr TileCfg kTiles[kNumTiles] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {256, 128},
                                        {128, 160}, {256, 160}, {128, 320},    // 6-8: N = 160*k layers
-                                       {256, 160}, {128, 160}, {256, 128},    // 9-13: bf16 16x16x32 path, wave tiles 64 x 80 / 64 x 64
-                                       {128, 128}, {64, 160}};
-constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2, 2};   // workgroups per CU (LDS-limited)
-constexpr bool kBf16Only[kNumTiles] = {false, false, false, false, false, false, false, false, false, true, true, true, true, true};
+                                       // 9-12: bf16 v_mfma_f32_16x16x32 path, wave tiles 64 x 80 / 64 x 64;
+                                       // the 8-wave ones (9, 11) ping-pong their two wave halves
+                                       {256, 160}, {128, 160}, {256, 128}, {128, 128}};
+constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2};   // workgroups per CU (LDS-limited)
+constexpr bool kBf16Only[kNumTiles] = {false, false, false, false, false, false, false, false, false, true, true, true, true};
 
 template <typename T>
 void launch_mode(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
@@ -172,8 +173,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // measured time one CU needs for one K-tile of that configuration with its resident
 // workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
-  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.0, 1.0, 0.8, 0.75, 0.6};   // bf16, per round per K-tile (resident WGs co-running)
-  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8, 8};   // launch + prologue + epilogue, in K-tiles
+  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80};   // bf16, per round per K-tile (resident WGs co-running)
+  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8};   // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
   static const bool no160 = getenv("LDM_GEMM_NO160") != nullptr;   // A/B switch for tools/
   const int bke = 128 / esize;
@@ -185,7 +186,8 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   for (int c = 1; c < kNumTiles; ++c) {
     if (p->tile > 0 && p->tile < kNumTiles && c != p->tile) continue;
     if (c == 5 && p->tile != 5) continue;   // experimental: only when forced
-    if (c >= 9 && c != 10 && p->tile != c) continue;   // measured no better than their 32x32x16 twins: only when forced
+    if (c == 12 && p->tile != c) continue;   // 128x128 on the 16x16x32 path: no better than tile 2, only when forced
+    if ((c == 1 || c == 7) && esize == 2 && p->tile != c) continue;   // bf16: their ping-ponged twins 11 / 9 are ~20 % faster
     if (c == 6 && esize == 2 && p->tile != 6) continue;   // bf16: tile 10 (same 128x160 tile, 64x80 wave tiles) is 10-14 % faster
     if (kBf16Only[c] && esize != 2) continue;
     if (kTiles[c].bn % 160 == 0 && p->tile != c && (p->N % kTiles[c].bn != 0 || no160)) continue;   // 160/320-column tiles: N = 160*k layers

@@ -85,7 +85,12 @@ __device__ __forceinline__ float apply_act(int act, float v) {
 // MF:   0 = v_mfma_f32_32x32x16 (wave tile = TM x TN blocks of 32x32)
 //       1 = v_mfma_f32_16x16x32_bf16 (bf16 only; wave tile = blocks of 16x16, e.g. 64 x 80: the
 //           N = 160*k layers get a 2.2x larger wave tile per LDS byte read than 32 x 160)
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int MF = 0>
+// ST:   1 = ping-pong the two halves of an 8-wave workgroup (waves w and w + 4 share a SIMD):
+//           waves 0-3 run {stage next tile, read fragments of tile t, MFMA tile t} in every
+//           barrier period, waves 4-7 run {MFMA tile t-1 (fragments kept in registers across the
+//           barrier), stage, read fragments of tile t}: on each SIMD one wave multiplies while the
+//           other stages and reads LDS, instead of both doing the same thing at the same time.
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int MF = 0, int ST = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // The body uses LDS address-space pointers and gfx950 inline asm, which only the
   // device pass can parse; the host pass just needs the launch stub.
@@ -291,23 +296,16 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // LDS-DMAs may still be in flight -- and tile t+2 goes to the stage tile t-1 was read from.
   if (nk > 0) issue_tile(kt_begin, 0);
   if (NSTAGE == 3 && nk > 1) issue_tile(kt_begin + 1, 1);
-  int st = 0;
-  for (int t = 0; t < nk; ++t) {
+  u32x4 fa[KS][TM], fb[KS][TN];
+  auto wait_tile = [&](int t) {                      // this wave's LDS-DMAs of tile t have landed
     if (NSTAGE == 3 && t + 1 < nk) {
       if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL - 1) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();
-    if (t + NSTAGE - 1 < nk) {
-      int sn = st + NSTAGE - 1;
-      sn = sn >= NSTAGE ? sn - NSTAGE : sn;
-      issue_tile(kt_begin + t + NSTAGE - 1, sn);
-    }
-    const char* cS = smem + st * STAGE;
-    st = st + 1 == NSTAGE ? 0 : st + 1;
-    u32x4 fa[KS][TM], fb[KS][TN];
+  };
+  auto read_frags = [&](const char* cS) {
 #pragma unroll
     for (int kg = 0; kg < KS; ++kg) {
 #pragma unroll
@@ -315,9 +313,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) fb[kg][j] = *(const u32x4*)(cS + offB[kg] + j * MB * 128);
     }
+  };
+  // (issuing the next tile's LDS-DMAs between the two halves of the MFMA block instead of in
+  // front of it was measured 3-5 % slower on the long-K convolutions and dropped)
+  auto multiply = [&]() {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kg = 0; kg < KS; ++kg)
+    for (int kg = 0; kg < KS; ++kg) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -329,7 +331,39 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
             mma32(acc[i][j], fa[kg][i], fb[kg][j], T());
           }
         }
+    }
     __builtin_amdgcn_s_setprio(0);
+  };
+  int st = 0;
+  const bool late = ST && wave >= NW / 2;            // wave-uniform (wave is a readfirstlane)
+  if (!late) {
+    for (int t = 0; t < nk; ++t) {
+      wait_tile(t);
+      __builtin_amdgcn_s_barrier();
+      int sn = st + NSTAGE - 1;
+      sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+      if (t + NSTAGE - 1 < nk) issue_tile(kt_begin + t + NSTAGE - 1, sn);
+      read_frags(smem + st * STAGE);
+      st = st + 1 == NSTAGE ? 0 : st + 1;
+      multiply();
+    }
+  } else {
+    // Late half.  Every wave passes the same nk barriers.  The fragments of tile t are read at
+    // the END of period t and drained (lgkmcnt(0)) before the next barrier, so the stage of
+    // tile t is free for the LDS-DMA of tile t + NSTAGE that any wave issues after that barrier.
+    for (int t = 0; t < nk; ++t) {
+      wait_tile(t);
+      __builtin_amdgcn_s_barrier();
+      int sn = st + NSTAGE - 1;
+      sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+      if (t > 0) multiply();                          // tile t - 1, from registers
+      if (t + NSTAGE - 1 < nk) issue_tile(kt_begin + t + NSTAGE - 1, sn);
+      read_frags(smem + st * STAGE);
+      st = st + 1 == NSTAGE ? 0 : st + 1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nk > 0) multiply();
   }
   __syncthreads();   // all waves done with the staging LDS before the epilogue reuses it
 

@@ -15,13 +15,12 @@ void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
     case 6: hipLaunchKernelGGL((gemm_kernel<T, 128, 160, 4, 1, MODE>), grid, dim3(256), 0, s, a); break;   // 4 waves x (32x160)
     case 7: hipLaunchKernelGGL((gemm_kernel<T, 256, 160, 8, 1, MODE>), grid, dim3(512), 0, s, a); break;   // 8 waves x (32x160)
     case 8: hipLaunchKernelGGL((gemm_kernel<T, 128, 320, 4, 2, MODE>), grid, dim3(512), 0, s, a); break;   // 8 waves x (32x160)
-    case 9: case 10: case 11: case 12: case 13:
+    case 9: case 10: case 11: case 12:
       if constexpr (sizeof(T) == 2) {
-        if (cfg == 9) hipLaunchKernelGGL((gemm_kernel<T, 256, 160, 4, 2, MODE, 1>), grid, dim3(512), 0, s, a);        // 8 waves x (64x80), 3-stage ring
-        else if (cfg == 10) hipLaunchKernelGGL((gemm_kernel<T, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, s, a);  // 4 waves x (64x80)
-        else if (cfg == 11) hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2, MODE, 1>), grid, dim3(512), 0, s, a);  // 8 waves x (64x64), 3-stage ring
-        else if (cfg == 12) hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, s, a);  // 4 waves x (64x64)
-        else hipLaunchKernelGGL((gemm_kernel<T, 64, 160, 1, 2, MODE, 1>), grid, dim3(128), 0, s, a);                  // 2 waves x (64x80)
+        if (cfg == 9) hipLaunchKernelGGL((gemm_kernel<T, 256, 160, 4, 2, MODE, 1, 1>), grid, dim3(512), 0, s, a);        // 8 waves x (64x80), 3-stage ring, ping-ponged halves
+        else if (cfg == 10) hipLaunchKernelGGL((gemm_kernel<T, 128, 160, 2, 2, MODE, 1>), grid, dim3(256), 0, s, a);     // 4 waves x (64x80), 2 workgroups per CU
+        else if (cfg == 11) hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2, MODE, 1, 1>), grid, dim3(512), 0, s, a);  // 8 waves x (64x64), 3-stage ring, ping-ponged halves
+        else hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, s, a);                    // 4 waves x (64x64), 2 workgroups per CU
       }
       break;
     default: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;

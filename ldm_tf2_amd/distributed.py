@@ -61,3 +61,23 @@ def max_over_ranks(value: float, device) -> float:
   t = torch.tensor([float(value)], dtype=torch.float64, device=device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   return float(t.item())
+
+
+def world_size() -> int:
+  """Rank count as torch.distributed reports it (1 when not initialised)."""
+  return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def backend_name() -> str:
+  """'nccl' is RCCL on ROCm; 'none' for a single process."""
+  return dist.get_backend() if (dist.is_available() and dist.is_initialized()) else "none"
+
+
+def gather_floats(value: float, device):
+  """One float per rank, in rank order, on every rank (bench.py: per-rank loop times)."""
+  if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    return [float(value)]
+  t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+  out = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
+  dist.all_gather_into_tensor(out, t)
+  return [float(v) for v in out.cpu()]

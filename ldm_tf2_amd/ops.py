@@ -129,8 +129,8 @@ _ACTIVE_CFG = None
 _PLAN_RECORD = None
 _TILE_DIMS = {1: (256, 128, 1), 2: (128, 128, 2), 3: (128, 64, 3), 4: (64, 64, 5), 6: (128, 160, 2),
               7: (256, 160, 1), 8: (128, 320, 1),       # BM, BN, resident workgroups per CU
-              10: (128, 160, 2), 12: (128, 128, 2), 13: (64, 160, 2)}   # bf16 16x16x32 MFMA path
-_BF16_TILES = (9, 10, 11, 12, 13)
+              9: (256, 160, 1), 10: (128, 160, 2), 11: (256, 128, 1), 12: (128, 128, 2)}   # bf16 16x16x32 MFMA path
+_BF16_TILES = (9, 10, 11, 12)
 
 
 def plan_key(p) -> str:
@@ -233,7 +233,7 @@ def plan_candidates(M, N, K, batch, act, dtype):
   ktiles = K // (64 if dtype == BF16 else 32)
   out = []
   for tile, (bm, bn, res) in _TILE_DIMS.items():
-    if act == ACT_GEGLU and tile not in (1, 2, 12):
+    if act == ACT_GEGLU and tile not in (1, 2, 11, 12):
       continue
     if tile in _BF16_TILES and dtype != BF16:
       continue

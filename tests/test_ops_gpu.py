@@ -36,11 +36,11 @@ def close(got, ref, dtype, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (64, 192, 1280), (1024, 64, 64), (700, 640, 128)])
 def test_linear(dev, dtype, tile, M, N, K):
   if tile >= 9 and dtype != torch.bfloat16:
-    pytest.skip("tiles 9-13 are the bf16 16x16x32 MFMA path")
+    pytest.skip("tiles 9-12 are the bf16 16x16x32 MFMA path")
   x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
   bias = rnd((N,), torch.float32, 3)
   res = rnd((M, N), dtype, 4)
@@ -72,7 +72,7 @@ def test_linear_act_splitk(dev, dtype, act):
     close(out, ref, dtype)
   if dtype == torch.bfloat16:
     # 16x16x32 MFMA tiles: every activation epilogue and the split-K slab layout
-    for tile in ((11, 12) if act == "geglu" else (9, 10, 11, 12, 13)):
+    for tile in ((11, 12) if act == "geglu" else (9, 10, 11, 12)):
       for split in (1, 4):
         out = torch.zeros(M, nout, dtype=dtype, device=dev)
         o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), act=code, split_k=split, tile=tile)
@@ -115,7 +115,7 @@ def test_conv3x3(dev, dtype, cfg):
   res = rnd((B, OH, OW, Cout), dtype, 6)
   ref = ref + res.float()
   wt = k.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous().to(dev)
-  bf = (9, 10, 11, 12, 13) if dtype == torch.bfloat16 else ()     # 16x16x32 MFMA tiles: bf16 only
+  bf = (9, 10, 11, 12) if dtype == torch.bfloat16 else ()     # 16x16x32 MFMA tiles: bf16 only
   for tile in (0, 1, 2, 3, 4, 6, 7, 8) + bf + (21, 22, 23):     # 1-11 implicit GEMM tiles, 21-23 halo tiles
     out = torch.zeros(B, OH, OW, Cout, dtype=dtype, device=dev)
     o.conv3x3(x.to(dev), wt, out, bias=bias.to(dev), stride=cfg["stride"], upsample=cfg["up"],

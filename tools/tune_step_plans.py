@@ -38,7 +38,9 @@ def main():
   dev = torch.device("cuda:0")
   dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
   cfg = BN.FULL
-  if not args.keep_plans:                      # second pass: start from the packaged table
+  # the table of THIS step configuration is the one being edited (UNet.forward activates the same)
+  ops.select_plans(2 * args.batch, args.latent, args.dtype)
+  if not args.keep_plans:                      # otherwise: refinement pass from the packaged table
     for k in list(ops.gemm_plans()):
       ops.set_plan(k, None)
   w = {"unet": Wt.init_weights(Wt.unet_manifest(**cfg["unet"]), seed=2, scope="unet"),
@@ -112,7 +114,9 @@ def main():
   print(f"tuned step: {final:.3f} ms (baseline {base:.3f})", flush=True)
   os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
   json.dump({"about": f"tools/tune_step_plans.py on MI355X, B={B}, latent {args.latent}, {args.dtype}: "
-                      f"step {base:.3f} -> {final:.3f} ms", "plans": plans}, open(args.out, "w"), indent=1)
+                      f"step {base:.3f} -> {final:.3f} ms",
+             "config": {"rows": 2 * B, "latent": args.latent, "dtype": args.dtype},
+             "plans": plans}, open(args.out, "w"), indent=1)
   print("wrote", args.out, flush=True)
 
 
