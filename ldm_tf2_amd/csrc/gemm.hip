@@ -33,6 +33,7 @@
 //     over all CUs; partial sums go to an f32 workspace and a second kernel
 //     reduces + applies the epilogue.
 #include "gemm_kernel.h"
+#include "gemm3_kernel.h"
 
 using namespace ldm_gemm_detail;
 
@@ -149,14 +150,18 @@ __global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(GemmArgs p) {
 
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
-constexpr int kNumTiles = 13;
+constexpr int kNumTiles = 15;
 constexpr TileCfg kTiles[kNumTiles] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {256, 128},
                                        {128, 160}, {256, 160}, {128, 320},    // 6-8: N = 160*k layers
                                        // 9-12: bf16 v_mfma_f32_16x16x32 path, wave tiles 64 x 80 / 64 x 64;
                                        // the 8-wave ones (9, 11) ping-pong their two wave halves
-                                       {256, 160}, {128, 160}, {256, 128}, {128, 128}};
-constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2};   // workgroups per CU (LDS-limited)
-constexpr bool kBf16Only[kNumTiles] = {false, false, false, false, false, false, false, false, false, true, true, true, true};
+                                       {256, 160}, {128, 160}, {256, 128}, {128, 128},
+                                       // 13, 14: persistent ping-pong kernel (gemm3_kernel.h): a workgroup walks
+                                       // several n-tiles of its 256-row panel, register epilogue
+                                       {256, 160}, {256, 128}};
+constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2, 1, 1};   // workgroups per CU (LDS-limited)
+constexpr bool kBf16Only[kNumTiles] = {false, false, false, false, false, false, false, false, false, true, true, true, true, true, true};
+constexpr int kFirstPersistent = 13;
 
 template <typename T>
 void launch_mode(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
@@ -173,8 +178,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // measured time one CU needs for one K-tile of that configuration with its resident
 // workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
-  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80};   // bf16, per round per K-tile (resident WGs co-running)
-  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8};   // launch + prologue + epilogue, in K-tiles
+  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80, 1.03, 0.97};   // bf16, per round per K-tile (resident WGs co-running)
+  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4};   // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
   static const bool no160 = getenv("LDM_GEMM_NO160") != nullptr;   // A/B switch for tools/
   const int bke = 128 / esize;
@@ -186,17 +191,19 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   for (int c = 1; c < kNumTiles; ++c) {
     if (p->tile > 0 && p->tile < kNumTiles && c != p->tile) continue;
     if (c == 5 && p->tile != 5) continue;   // experimental: only when forced
+    if (c >= kFirstPersistent && p->tile != c) continue;   // persistent kernel: only when forced (plan tables)
     if (c == 12 && p->tile != c) continue;   // 128x128 on the 16x16x32 path: no better than tile 2, only when forced
     if ((c == 1 || c == 7) && esize == 2 && p->tile != c) continue;   // bf16: their ping-ponged twins 11 / 9 are ~20 % faster
     if (c == 6 && esize == 2 && p->tile != 6) continue;   // bf16: tile 10 (same 128x160 tile, 64x80 wave tiles) is 10-14 % faster
     if (kBf16Only[c] && esize != 2) continue;
     if (kTiles[c].bn % 160 == 0 && p->tile != c && (p->N % kTiles[c].bn != 0 || no160)) continue;   // 160/320-column tiles: N = 160*k layers
     if (p->out2 && p->n_split % kTiles[c].bn != 0) continue;                        // every tile on one side of n_split
-    if (geglu && c > 2 && c != 5 && c != 11 && c != 12) continue;
+    if (geglu && c > 2 && c != 5 && c != 11 && c != 12 && c != 14) continue;
     const TileCfg t = kTiles[c];
     const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
     for (int split : kSplits) {
       if (p->split_k > 0 && split != p->split_k) continue;
+      if (c >= kFirstPersistent && split > 1) continue;   // the persistent kernel does not split K
       // split-K only rescues launches that cannot fill the machine once, and must fit
       // the caller's workspace
       if (split > 1 && (p->batch != 1 || ktiles / split < 4 || tiles >= 256.0 * kResident[c] ||
@@ -317,8 +324,50 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
                       ((uintptr_t)p->out2 % 16) == 0, "ldm_gemm: out2 geometry (rows2 %% 4, M %% rows2, ld2 / stride2 %% 4, alignment)");
     split = 1;
   }
-  if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5 || cfg == 11 || cfg == 12, "ldm_gemm: GEGLU needs a tile whose width is a multiple of 64 (1, 2, 5, 11, 12)");
+  if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5 || cfg == 11 || cfg == 12 || cfg == 14, "ldm_gemm: GEGLU needs a tile whose width is a multiple of 64 (1, 2, 5, 11, 12)");
   LDM_CHECK_ARG(!kBf16Only[cfg] || esize == 2, "ldm_gemm: tile %d is bf16 only", cfg);
+  if (cfg >= kFirstPersistent) {
+    // persistent ping-pong kernel: bf16 in/out, row-major 16-byte-aligned output, whole n-tiles
+    const int bn = kTiles[cfg].bn;
+    auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    LDM_CHECK_ARG(p->dtype == LDM_BF16 && p->out_dtype == LDM_BF16 && p->batch == 1 && p->ldc_n == 1 && !p->out2 &&
+                      !p->ln_out && split <= 1 && p->N % bn == 0 && p->ldc_m % 8 == 0 && al16(p->out) &&
+                      (!p->residual || (p->ldr % 4 == 0 && al16(p->residual))) && (!p->bias || al16(p->bias)) &&
+                      (!p->addend || (al16(p->addend) && p->add_ld % 4 == 0)),
+                  "ldm_gemm: tile %d (persistent) needs bf16 in/out, batch 1, a row-major 16-byte-aligned output, "
+                  "N %% %d == 0, no split-K / out2 / ln_out", cfg, bn);
+    Gemm3Args g;
+    memset(&g, 0, sizeof(g));
+    g.a = (const char*)p->a; g.w = (const char*)p->w; g.bias = p->bias; g.addend = p->addend;
+    g.residual = (const char*)p->residual; g.out = (char*)p->out;
+    g.lda = p->lda; g.ldr = p->ldr; g.ldc = p->ldc_m; g.add_ld = p->add_ld;
+    g.a_bytes = (uint32_t)a_bytes; g.w_bytes = (uint32_t)w_bytes;
+    g.M = p->M; g.N = p->N; g.K = p->K; g.add_rows = p->add_rows > 0 ? p->add_rows : 1;
+    g.conv = p->conv; g.H = p->H; g.W = p->W; g.Cin = p->Cin; g.OH = p->OH; g.OW = p->OW;
+    g.stride = p->stride; g.upsample = p->upsample; g.pad = p->no_lead_pad ? 0 : 1;
+    g.act = p->act;
+    LDM_CHECK_ARG(p->alpha == 1.0f, "ldm_gemm: tile %d (persistent) needs alpha == 1", cfg);
+    { static const int dbg = getenv("LDM_G3_DEBUG") ? atoi(getenv("LDM_G3_DEBUG")) : 0; g.dbg = dbg; }
+    g.ktiles = p->K / 64;
+    g.panels = cdiv(p->M, 256);
+    g.ntiles = p->N / bn;
+    // workgroups per panel: fill the 256 CUs about once, at most one workgroup per n-tile
+    int nsplit = p->split_k < 0 ? -p->split_k : (256 + g.panels / 2) / g.panels;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > g.ntiles) nsplit = g.ntiles;
+    g.tiles_per_wg = cdiv(g.ntiles, nsplit);
+    g.nsplit = cdiv(g.ntiles, g.tiles_per_wg);
+    dim3 grid3((unsigned)(g.panels * g.nsplit));
+    hipStream_t s3 = (hipStream_t)stream;
+    const int epi = epi_code(p->bias != nullptr, p->addend != nullptr, p->residual != nullptr, p->act);
+    bool ok;
+    if (!p->conv) ok = launch_gemm3<0>(bn / 32, epi, g, grid3, s3);
+    else if (!p->upsample) ok = launch_gemm3<1>(bn / 32, epi, g, grid3, s3);
+    else ok = launch_gemm3<2>(bn / 32, epi, g, grid3, s3);
+    LDM_CHECK_ARG(ok, "ldm_gemm: tile %d (persistent) has no kernel for this epilogue (bias %d addend %d residual %d act %d)",
+                  cfg, p->bias != nullptr, p->addend != nullptr, p->residual != nullptr, p->act);
+    return ldm_launch_status("ldm_gemm(persistent)");
+  }
   GemmArgs a;
   memset(&a, 0, sizeof(a));
   a.a = (const char*)p->a; a.w = (const char*)p->w; a.bias = p->bias; a.addend = p->addend;

@@ -1,0 +1,385 @@
+// Persistent ping-pong GEMM / implicit-GEMM 3x3 convolution for gfx950, bf16 (tiles 13 / 14 of
+// ldm_gemm).  Same operand formats and LDS image as gemm_kernel.h (A rows and W^T rows
+// K-contiguous, 128-byte K-tiles, XOR-swizzled 16-byte chunks, LDS-DMA staging with the hardware
+// range check as zero padding); what differs is the schedule around them:
+//
+//   * a workgroup = 8 waves owns a 256-row panel of the output and walks a RANGE of n-tiles of
+//     it.  The 3-stage LDS ring never drains between tiles: the first K-tiles of tile n+1 are
+//     already in flight while tile n's last K-tiles are multiplied (a non-persistent launch pays
+//     one pipeline fill + drain per tile: ~8 K-tile times for the 5-20 K-tiles of the
+//     transformer GEMMs);
+//   * the two wave halves are ping-ponged (waves w and w+4 share a SIMD): waves 0-3 run
+//     {stage, read fragments of step s, MFMA step s} in a barrier period, waves 4-7 run {MFMA
+//     step s-1 from registers, stage, read fragments of step s};
+//   * the epilogue of tile n runs right AFTER the first barrier of tile n+1, straight from the
+//     accumulators (no LDS round trip, no workgroup barrier): each half's epilogue overlaps the
+//     other half's MFMAs.  The MFMA is issued with the operands swapped (D = W_frag x A_frag), so
+//     a lane owns ONE output row m and 4 consecutive columns n per 16x16 block; two blocks are
+//     exchanged with v_permlane16_swap so that every lane stores 16 contiguous bytes.
+//     bias / per-sample addend (timestep embedding) / GELU, SiLU, GEGLU / residual are applied in
+//     f32 on the way.
+#pragma once
+#include "gemm_kernel.h"
+
+namespace ldm_gemm_detail {
+
+struct Gemm3Args {
+  const char* a;
+  const char* w;
+  const float* bias;
+  const float* addend;
+  const char* residual;
+  char* out;
+  int64_t lda, ldr, ldc, add_ld;
+  uint32_t a_bytes, w_bytes;
+  int M, N, K;
+  int add_rows;
+  int conv, H, W, Cin, OH, OW, stride, upsample, pad;
+  int act;
+  int ktiles;         // K / 64
+  int panels;         // ceil(M / 256)
+  int ntiles;         // N / BN
+  int nsplit;         // workgroups per panel
+  int tiles_per_wg;   // ceil(ntiles / nsplit)
+  int dbg;            // timing ablations (LDM_G3_DEBUG): 1 = no stores, 2 = no epilogue, 4 = no MFMA, 8 = no staging
+};
+
+// Epilogue variant, a compile-time constant: a runtime "is there a bias / residual" test around
+// each epilogue load makes the compiler branch and drain the memory pipeline per load.
+//   bit 0 bias, bit 1 per-group addend, bit 2 residual, bits 3-4 activation (LDM_ACT_* code)
+constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4;
+constexpr int epi_code(bool bias, bool add, bool res, int act) { return (bias ? 1 : 0) | (add ? 2 : 0) | (res ? 4 : 0) | (act << 3); }
+
+// BN = 32 * TN columns per n-tile; waves 4 (M) x 2 (N); wave tile 64 x (16 TN)
+template <int TN, int MODE, int EPI>
+__global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 32 * TN, WM = 4, WN = 2, NW = 8;
+  constexpr int WTM = 64, WTN = 16 * TN, TM = 4;
+  constexpr int NIB = BN / 8;
+  constexpr int LA = BM / (8 * NW), LB = (NIB + NW - 1) / NW, LBF = NIB / NW;
+  constexpr int NL = LA + LB;
+  constexpr int ES = 2;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int NSTAGE = 3;
+  static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int panel = bid / p.nsplit, sp = bid - panel * p.nsplit;
+  const int nt_begin = sp * p.tiles_per_wg;
+  const int ntl = min(p.ntiles, nt_begin + p.tiles_per_wg) - nt_begin;   // n-tiles of this workgroup
+  if (ntl <= 0) return;                                                  // (whole workgroup: uniform)
+  const int m0 = panel * BM;
+  const int nk = p.ktiles;
+  const int S = ntl * nk;                                                // pipeline steps
+
+  const __amdgpu_buffer_rsrc_t rsA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.a), 0, p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w), 0, p.w_bytes, 0x00020000);
+
+  // ---- per-lane staging geometry (as gemm_kernel.h) -------------------------------------
+  int a_base[LA], a_mask[LA], a_aux[LA];
+#pragma unroll
+  for (int i = 0; i < LA; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int ck = (lane & 7) ^ ((row >> 1) & 7);
+    const int m = m0 + row;
+    a_base[i] = MODE == 0 ? (int)kOOB : 0; a_mask[i] = 0; a_aux[i] = 0;
+    if (m < p.M) {
+      if constexpr (MODE != 0) {
+        const int ohw = p.OH * p.OW;
+        const int b = m / ohw, rem = m - b * ohw;
+        const int oy = rem / p.OW, ox = rem - oy * p.OW;
+        const int iy0 = oy * p.stride - p.pad, ix0 = ox * p.stride - p.pad;
+        const int Hs = MODE == 2 ? p.H * 2 : p.H, Ws = MODE == 2 ? p.W * 2 : p.W;
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = iy0 + t / 3, ix = ix0 + t % 3;
+          if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) mask |= 1 << t;
+        }
+        a_mask[i] = mask;
+        if constexpr (MODE == 2) {
+          a_base[i] = (int)((int64_t)b * p.H * p.W * p.lda * ES) + ck * 16;
+          a_aux[i] = (iy0 << 16) | (ix0 & 0xffff);
+        } else {
+          a_base[i] = (int)(((int64_t)(b * p.H + iy0) * p.W + ix0) * p.lda * ES) + ck * 16;
+        }
+      } else {
+        a_base[i] = (int)((int64_t)m * p.lda * ES) + ck * 16;
+      }
+    }
+  }
+  int b_base[LB];
+#pragma unroll
+  for (int i = 0; i < LB; ++i) {
+    const int row = (i * NW + wave) * 8 + (lane >> 3);
+    const int ck = (lane & 7) ^ ((row >> 1) & 7);
+    const int n = nt_begin * BN + row;
+    b_base[i] = (row < BN) ? (int)((int64_t)n * p.K * ES) + ck * 16 : (int)kOOB;
+  }
+  const bool b_last = LB == LBF || (LBF * NW + wave) < NIB;
+  const int row_pitch = (int)(p.lda * ES);
+  const int line_pitch = p.W * row_pitch;
+  const int tile_pitch = BN * p.K * ES;             // bytes between consecutive n-tiles of W^T
+
+  // step -> LDS-DMAs of (n-tile `tl` of this workgroup, K-tile kt) into `stage`
+  auto issue_tile = [&](int tl, int kt, int stage) {
+    char* dA = smem + stage * STAGE + wave * 1024;
+    char* dB = dA + BM * 128;
+    int kb;
+    if constexpr (MODE != 0) {
+      const int cc = kt / 9;
+      const int tap = kt - cc * 9;
+      const int cib = cc * 128;
+      kb = tap * p.Cin * ES + cib;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      if constexpr (MODE == 2) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+          const int iy = ((a_aux[i] >> 16) + kh) >> 1;
+          const int ix = ((int)(short)(a_aux[i] & 0xffff) + kw) >> 1;
+          const uint32_t off = (uint32_t)(a_base[i] + iy * line_pitch + ix * row_pitch + cib);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dA + i * NW * 1024), 16,
+                                                   ((a_mask[i] >> tap) & 1) ? off : kOOB, 0, 0, 0);
+        }
+      } else {
+        const int toff = kh * line_pitch + kw * row_pitch + cib;
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+          const uint32_t off = (uint32_t)(a_base[i] + toff);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dA + i * NW * 1024), 16,
+                                                   ((a_mask[i] >> tap) & 1) ? off : kOOB, 0, 0, 0);
+        }
+      }
+    } else {
+      kb = kt * 128;
+#pragma unroll
+      for (int i = 0; i < LA; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(dA + i * NW * 1024), 16,
+                                                 (uint32_t)a_base[i] + (uint32_t)kb, 0, 0, 0);
+    }
+    const uint32_t wb = (uint32_t)kb + (uint32_t)tl * (uint32_t)tile_pitch;
+#pragma unroll
+    for (int i = 0; i < LBF; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dB + i * NW * 1024), 16,
+                                               (uint32_t)b_base[i] + wb, 0, 0, 0);
+    if constexpr (LB != LBF) {
+      if (b_last)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dB + LBF * NW * 1024), 16,
+                                                 (uint32_t)b_base[LBF] + wb, 0, 0, 0);
+    }
+  };
+
+  f32x4 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  zero_acc();
+
+  const int lr = lane & 15, lh = lane >> 4;
+  const int sw = (lr >> 1) & 7;
+  int offA[2], offB[2];
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {
+    const int coff = ((kg * 4 + lh) ^ sw) << 4;
+    offA[kg] = (wm * WTM + lr) * 128 + coff;
+    offB[kg] = BM * 128 + (wn * WTN + lr) * 128 + coff;
+  }
+
+  u32x4 fa[2][TM], fb[2][TN];
+  auto read_frags = [&](const char* cS) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[kg][i] = *(const u32x4*)(cS + offA[kg] + i * 16 * 128);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[kg][j] = *(const u32x4*)(cS + offB[kg] + j * 16 * 128);
+    }
+  };
+  // operands SWAPPED: D[n][m] = sum_k W[n][k] A[m][k]; lane l then holds, for block (i, j),
+  // output row m = 16 i + (l & 15) and columns n = 16 j + 4 (l >> 4) + r, r = 0..3
+  auto multiply = [&]() {
+    if (p.dbg & 4) return;
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[kg][j]),
+                                                              __builtin_bit_cast(bf16x8, fa[kg][i]), acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+
+  // ---- register epilogue of one n-tile ----------------------------------------------------
+  constexpr bool HB = (EPI & kEpiBias) != 0, HA = (EPI & kEpiAdd) != 0, HR = (EPI & kEpiRes) != 0;
+  constexpr int ACT = EPI >> 3;
+  constexpr bool GEGLU = ACT == LDM_ACT_GEGLU;
+  static_assert(!GEGLU || TN == 4, "GEGLU: the wave tile must be one 64-row block of the interleaved weights");
+  auto epilogue = [&](int tl) {
+    if (p.dbg & 2) return;
+    const int n_w = (nt_begin + tl) * BN + wn * WTN;          // first column of this wave's tile
+    const int g = lh;
+    // All global loads of the epilogue are issued in batches ahead of their use (beside LDS-DMAs
+    // the compiler waits vmcnt(0) at the first use of an ordinary load).
+    f32x4 bv[TN];                                            // bias of this lane's 4 columns per block
+    if constexpr (HB) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(p.bias + n_w + 16 * j + 4 * g);
+    }
+    constexpr int NOB = GEGLU ? TN / 2 : TN;                 // output blocks per row
+    const int n_o = GEGLU ? (n_w >> 1) : n_w;                // first OUTPUT column of this wave's tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * WTM + 16 * i + lr;
+      const bool valid = m < p.M;
+      const int mc = valid ? m : p.M - 1;
+      f32x4 av[TN];
+      if constexpr (HA) {
+        const float* ad = p.addend + (int64_t)(mc / p.add_rows) * p.add_ld + n_w + 4 * g;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) av[j] = *(const f32x4*)(ad + 16 * j);
+      }
+      u32x2 rv[NOB];
+      if constexpr (HR) {
+        const bf16_t* rr = (const bf16_t*)p.residual + (int64_t)mc * p.ldr + n_o + 4 * g;
+#pragma unroll
+        for (int j = 0; j < NOB; ++j) rv[j] = *(const u32x2*)(rr + 16 * j);
+      }
+      // value of block j, registers r = 0..3 (columns n_w + 16 j + 4 g + r), before the residual
+      auto block = [&](int j, float (&v)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if constexpr (HB) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
+        }
+        if constexpr (HA) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += av[j][r];
+        }
+      };
+      auto finish = [&](int jo, float (&v)[4], uint32_t (&pk)[2]) {   // + residual of output block jo, pack
+        if constexpr (HR) {
+          v[0] += __uint_as_float(rv[jo][0] << 16); v[1] += __uint_as_float(rv[jo][0] & 0xffff0000u);
+          v[2] += __uint_as_float(rv[jo][1] << 16); v[3] += __uint_as_float(rv[jo][1] & 0xffff0000u);
+        }
+        pk[0] = pack_bf2(v[0], v[1]);
+        pk[1] = pack_bf2(v[2], v[3]);
+      };
+      bf16_t* orow = (bf16_t*)p.out + (int64_t)mc * p.ldc + n_o;
+      uint32_t pk[NOB][2];
+      if constexpr (GEGLU) {
+        // wave tile = one 64-row block of the interleaved GEGLU weights: blocks 0, 1 = value,
+        // blocks 2, 3 = gate; output columns (n_w / 2) + 16 j + 4 g + r
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          float v[4], gt[4];
+          block(j, v);
+          block(j + 2, gt);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= gelu_erf_f(gt[r]);
+          finish(j, v, pk[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float v[4];
+          block(j, v);
+          if constexpr (ACT == LDM_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
+          } else if constexpr (ACT == LDM_ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+          }
+          finish(j, v, pk[j]);
+        }
+      }
+      // 16-lane groups g: X = block j, Y = block j+1.  After the swaps group 0 holds columns 0-7
+      // of block j, group 1 columns 0-7 of block j+1, group 2 columns 8-15 of block j, group 3
+      // columns 8-15 of block j+1: 16 contiguous bytes per lane.
+#pragma unroll
+      for (int j = 0; j + 1 < NOB; j += 2) {
+        const auto s0 = __builtin_amdgcn_permlane16_swap(pk[j][0], pk[j + 1][0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(pk[j][1], pk[j + 1][1], false, false);
+        if (valid && !(p.dbg & 1)) {
+          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+          *(u32x4*)(orow + 16 * (j + (g & 1)) + 8 * (g >> 1)) = o;
+        }
+      }
+      if constexpr (NOB & 1) {
+        if (valid && !(p.dbg & 1)) {
+          const u32x2 o = {pk[NOB - 1][0], pk[NOB - 1][1]};
+          *(u32x2*)(orow + 16 * (NOB - 1) + 4 * g) = o;
+        }
+      }
+    }
+  };
+
+  // ---- pipeline ---------------------------------------------------------------------------
+  int is_tl = 0, is_kt = 0;                          // next step to stage
+  auto issue_next = [&](int stage) {
+    if (!(p.dbg & 8)) issue_tile(is_tl, is_kt, stage);
+    if (++is_kt == nk) { is_kt = 0; ++is_tl; }
+  };
+  issue_next(0);
+  if (S > 1) issue_next(1);
+  int st = 0, ck = 0, ctl = 0;                       // ring slot, K-tile and n-tile of step s
+  const bool late = wave >= NW / 2;
+  // Iteration s = one barrier period.  Early half: stage step s+2, read step s, multiply step s.
+  // Late half: multiply step s-1 (fragments kept in registers), stage, read step s, drain the
+  // reads (the stage may be overwritten after the next barrier).  A tile that completed with
+  // step s-1 gets its epilogue right after the barrier of period s in BOTH halves, so each
+  // half's epilogue runs beside the other half's MFMAs.  Iteration S only finishes the last tile.
+  for (int s = 0; s <= S; ++s) {
+    if (s < S) {
+      if (s + 1 < S) {                               // this wave's LDS-DMAs of step s have landed
+        if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    if (late && s > 0) multiply();
+    if (ck == 0 && s > 0) { epilogue(ctl - 1); zero_acc(); }
+    if (s == S) break;
+    int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+    if (s + 2 < S) issue_next(sn);
+    read_frags(smem + st * STAGE);
+    st = st + 1 == NSTAGE ? 0 : st + 1;
+    if (++ck == nk) { ck = 0; ++ctl; }
+    if (!late) {
+      multiply();
+    } else {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#endif
+}
+
+// returns false when the (tile, epilogue) combination is not instantiated
+template <int MODE>
+bool launch_gemm3(int tn, int epi, const Gemm3Args& a, dim3 grid, hipStream_t s);
+
+}  // namespace ldm_gemm_detail

@@ -129,8 +129,10 @@ _ACTIVE_CFG = None
 _PLAN_RECORD = None
 _TILE_DIMS = {1: (256, 128, 1), 2: (128, 128, 2), 3: (128, 64, 3), 4: (64, 64, 5), 6: (128, 160, 2),
               7: (256, 160, 1), 8: (128, 320, 1),       # BM, BN, resident workgroups per CU
-              9: (256, 160, 1), 10: (128, 160, 2), 11: (256, 128, 1), 12: (128, 128, 2)}   # bf16 16x16x32 MFMA path
-_BF16_TILES = (9, 10, 11, 12)
+              9: (256, 160, 1), 10: (128, 160, 2), 11: (256, 128, 1), 12: (128, 128, 2),   # bf16 16x16x32 MFMA path
+              13: (256, 160, 1), 14: (256, 128, 1)}     # persistent ping-pong kernel (no split-K, N % BN == 0)
+_BF16_TILES = (9, 10, 11, 12, 13, 14)
+_PERSISTENT_TILES = (13, 14)
 
 
 def plan_key(p) -> str:
@@ -233,13 +235,17 @@ def plan_candidates(M, N, K, batch, act, dtype):
   ktiles = K // (64 if dtype == BF16 else 32)
   out = []
   for tile, (bm, bn, res) in _TILE_DIMS.items():
-    if act == ACT_GEGLU and tile not in (1, 2, 11, 12):
+    if act == ACT_GEGLU and tile not in (1, 2, 11, 12, 14):
       continue
     if tile in _BF16_TILES and dtype != BF16:
       continue
     if bn % 160 == 0 and N % bn != 0:
       continue
     tiles = -(-M // bm) * -(-N // bn) * batch
+    if tile in _PERSISTENT_TILES:
+      if N % bn == 0 and batch == 1 and tiles >= 128:
+        out.append((tile, 1))
+      continue
     out.append((tile, 1))
     if batch == 1 and tiles < 256 * res:         # sub-round launches: split-K candidates
       out += [(tile, s) for s in (2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24)

@@ -497,3 +497,87 @@ def test_conv3x3_small_in_paths(dev, dtype, B, H, W, Cin, Cout):
   torch.cuda.synchronize()
   close(out, O.conv2d(x, k, b), dtype)
   assert (wide[..., :64].float() == 7.0).all()
+
+
+# ---- persistent ping-pong kernel (tiles 13 = 256x160, 14 = 256x128; gemm3_kernel.h) ---------------
+@pytest.mark.parametrize("tile,N", [(13, 320), (13, 1280), (14, 384), (14, 1152)])
+@pytest.mark.parametrize("M,K,nsplit", [(300, 320, 0), (1000, 384, 1), (777, 64, 2), (4096, 640, 0)])
+def test_persistent_linear(dev, tile, N, M, K, nsplit):
+  """Several n-tiles per workgroup (nsplit = 1: ALL n-tiles of a panel in one workgroup), ragged M,
+  one-K-tile problems (every step is a tile boundary); epilogues: none, bias, bias + residual."""
+  o = ops()
+  dtype = torch.bfloat16
+  x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+  bias = rnd((N,), torch.float32, 3)
+  res = rnd((M, N), dtype, 4)
+  y = x.float() @ w.float().t()
+  for b, r in ((None, None), (bias, None), (bias, res), (None, res)):
+    out = torch.full((M + 3, N), 7.0, dtype=dtype, device=dev)          # rows beyond M must stay untouched
+    o.linear(x.to(dev), w.to(dev), out[:M], bias=None if b is None else b.to(dev),
+             residual=None if r is None else r.to(dev), tile=tile, split_k=-nsplit)
+    ref = y + (0 if b is None else b) + (0 if r is None else r.float())
+    close(out[:M], ref, dtype)
+    assert bool((out[M:] == 7.0).all())
+
+
+@pytest.mark.parametrize("act", ["gelu", "silu", "geglu"])
+def test_persistent_linear_activations(dev, act):
+  o = ops()
+  dtype = torch.bfloat16
+  M, N, K = 520, 1280, 320
+  x, w = rnd((M, K), dtype, 1), rnd((N, K), dtype, 2, K ** -0.5)
+  bias = rnd((N,), torch.float32, 3)
+  y = x.float() @ w.float().t() + bias
+  code = {"gelu": o.ACT_GELU, "silu": o.ACT_SILU, "geglu": o.ACT_GEGLU}[act]
+  if act == "geglu":
+    yv = y.reshape(M, N // 64, 2, 32)
+    ref, nout = (yv[:, :, 0] * O.gelu(yv[:, :, 1])).reshape(M, N // 2), N // 2
+  else:
+    ref, nout = {"gelu": O.gelu, "silu": O.silu}[act](y), N
+  for tile in ((14,) if act == "geglu" else (13, 14)):
+    for nsplit in (0, 1, 3):
+      out = torch.zeros(M, nout, dtype=dtype, device=dev)
+      o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), act=code, tile=tile, split_k=-nsplit)
+      close(out, ref, dtype)
+  from ldm_tf2_amd._lib import LdmHipError
+  with pytest.raises(LdmHipError):                                       # N not a whole number of n-tiles
+    o.linear(x.to(dev), w[:200].contiguous().to(dev), torch.zeros(M, 200, dtype=dtype, device=dev), tile=13)
+  with pytest.raises(LdmHipError):                                       # bf16 only
+    o.linear(x.float().to(dev), w.float().to(dev), torch.zeros(M, N, device=dev), tile=13)
+  with pytest.raises(LdmHipError):                                       # epilogue combination not built: loud
+    o.linear(x.to(dev), w.to(dev), torch.zeros(M, N, dtype=dtype, device=dev), bias=bias.to(dev), act=o.ACT_GELU,
+             residual=torch.zeros(M, N, dtype=dtype, device=dev), tile=13)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=3, H=16, W=16, Cin=128, Cout=320, stride=1, up=False),
+    dict(B=2, H=32, W=32, Cin=64, Cout=128, stride=1, up=False),
+    dict(B=5, H=8, W=8, Cin=192, Cout=640, stride=1, up=False),          # ragged M (320 rows), 27 K-tiles
+    dict(B=2, H=16, W=16, Cin=64, Cout=160, stride=2, up=False),
+    dict(B=2, H=8, W=8, Cin=128, Cout=256, stride=1, up=True),
+])
+def test_persistent_conv3x3(dev, cfg):
+  o = ops()
+  dtype = torch.bfloat16
+  B, H, W, Cin, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+  x = rnd((B, H, W, Cin), dtype, 1)
+  k = rnd((3, 3, Cin, Cout), dtype, 2, (9 * Cin) ** -0.5)
+  bias = rnd((Cout,), torch.float32, 3)
+  addend = rnd((B, Cout), torch.float32, 4)
+  xin = O.upsample_nearest2x(x.float()) if cfg["up"] else x.float()
+  base = O.conv2d(xin, k.float(), bias, stride=cfg["stride"])
+  OH, OW = base.shape[1], base.shape[2]
+  res = rnd((B, OH, OW, Cout), dtype, 6)
+  wt = k.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous().to(dev)
+  for tile in (13, 14):
+    if Cout % (160 if tile == 13 else 128):
+      continue
+    for nsplit in (0, 1):
+      # the three conv epilogues of the U-Net: bias (down / up), bias + temb addend (conv1), bias + residual (conv2)
+      for ad, rs in ((None, None), (addend, None), (None, res)):
+        out = torch.zeros(B, OH, OW, Cout, dtype=dtype, device=dev)
+        o.conv3x3(x.to(dev), wt, out, bias=bias.to(dev), stride=cfg["stride"], upsample=cfg["up"],
+                  addend=None if ad is None else ad.to(dev), residual=None if rs is None else rs.to(dev),
+                  tile=tile, split_k=-nsplit)
+        ref = base + (0 if ad is None else ad[:, None, None, :]) + (0 if rs is None else rs.float())
+        close(out, ref, dtype)
