@@ -285,7 +285,6 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
         pk[0] = pack_bf2(v[0], v[1]);
         pk[1] = pack_bf2(v[2], v[3]);
       };
-      bf16_t* orow = (bf16_t*)p.out + (int64_t)mc * p.ldc + n_o;
       uint32_t pk[NOB][2];
       if constexpr (GEGLU) {
         // wave tile = one 64-row block of the interleaved GEGLU weights: blocks 0, 1 = value,
@@ -316,21 +315,34 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       }
       // 16-lane groups g: X = block j, Y = block j+1.  After the swaps group 0 holds columns 0-7
       // of block j, group 1 columns 0-7 of block j+1, group 2 columns 8-15 of block j, group 3
-      // columns 8-15 of block j+1: 16 contiguous bytes per lane.
+      // columns 8-15 of block j+1: 16 contiguous bytes per lane, but the four 16-byte pieces of
+      // one row's 64 bytes sit in lanes c, c+16, c+32, c+48.  A store instruction is coalesced
+      // per 4 ADJACENT lanes, so the pieces are moved (ds_bpermute: crossbar only, no LDS memory)
+      // to lane 4 * row + piece first: every quad then writes 64 contiguous bytes (16 requests
+      // per instruction instead of 64).
+      const int row2 = lane >> 2, pc = lane & 3;              // after the move: row inside the block, piece
+      const int src = (16 * ((pc >> 1) | ((pc & 1) << 1)) + row2) * 4;   // piece 0..3 <- group 0, 2, 1, 3
+      const int m2 = m0 + wm * WTM + 16 * i + row2;
+      const bool valid2 = m2 < p.M && !(p.dbg & 1);
+      bf16_t* orow2 = (bf16_t*)p.out + (int64_t)(valid2 ? m2 : 0) * p.ldc + n_o;
 #pragma unroll
       for (int j = 0; j + 1 < NOB; j += 2) {
         const auto s0 = __builtin_amdgcn_permlane16_swap(pk[j][0], pk[j + 1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(pk[j][1], pk[j + 1][1], false, false);
-        if (valid && !(p.dbg & 1)) {
-          const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
-          *(u32x4*)(orow + 16 * (j + (g & 1)) + 8 * (g >> 1)) = o;
-        }
+        u32x4 o;
+        o[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s0[0]);
+        o[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s1[0]);
+        o[2] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s0[1]);
+        o[3] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s1[1]);
+        if (valid2) *(u32x4*)(orow2 + 16 * j + 8 * pc) = o;
       }
       if constexpr (NOB & 1) {
-        if (valid && !(p.dbg & 1)) {
-          const u32x2 o = {pk[NOB - 1][0], pk[NOB - 1][1]};
-          *(u32x2*)(orow + 16 * (NOB - 1) + 4 * g) = o;
-        }
+        // last block alone: 8 bytes per lane (columns 4 g .. 4 g + 3); same move, pieces in group order
+        const int src1 = (16 * pc + row2) * 4;
+        u32x2 o;
+        o[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(src1, (int)pk[NOB - 1][0]);
+        o[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(src1, (int)pk[NOB - 1][1]);
+        if (valid2) *(u32x2*)(orow2 + 16 * (NOB - 1) + 4 * pc) = o;
       }
     }
   };
@@ -345,36 +357,49 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   if (S > 1) issue_next(1);
   int st = 0, ck = 0, ctl = 0;                       // ring slot, K-tile and n-tile of step s
   const bool late = wave >= NW / 2;
-  // Iteration s = one barrier period.  Early half: stage step s+2, read step s, multiply step s.
+  // One barrier period per step s.  Early half: stage step s+2, read step s, multiply step s.
   // Late half: multiply step s-1 (fragments kept in registers), stage, read step s, drain the
   // reads (the stage may be overwritten after the next barrier).  A tile that completed with
   // step s-1 gets its epilogue right after the barrier of period s in BOTH halves, so each
-  // half's epilogue runs beside the other half's MFMAs.  Iteration S only finishes the last tile.
-  for (int s = 0; s <= S; ++s) {
-    if (s < S) {
-      if (s + 1 < S) {                               // this wave's LDS-DMAs of step s have landed
-        if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL - 1) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();
-    }
-    if (late && s > 0) multiply();
-    if (ck == 0 && s > 0) { epilogue(ctl - 1); zero_acc(); }
-    if (s == S) break;
-    int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
-    if (s + 2 < S) issue_next(sn);
-    read_frags(smem + st * STAGE);
-    st = st + 1 == NSTAGE ? 0 : st + 1;
-    if (++ck == nk) { ck = 0; ++ctl; }
-    if (!late) {
-      multiply();
+  // half's epilogue runs beside the other half's MFMAs.  (Two loops, not one with `late` tests
+  // inside: the merged loop keeps the fragments live across the epilogue and spills.)
+  auto wait_step = [&](int s) {                      // this wave's LDS-DMAs of step s have landed
+    if (s + 1 < S) {
+      if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL - 1) : "memory");
     } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  if (!late) {
+    for (int s = 0; s < S; ++s) {
+      wait_step(s);
+      __builtin_amdgcn_s_barrier();
+      if (ck == 0 && s > 0) { epilogue(ctl - 1); zero_acc(); }
+      int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+      if (s + 2 < S) issue_next(sn);
+      read_frags(smem + st * STAGE);
+      multiply();
+      st = st + 1 == NSTAGE ? 0 : st + 1;
+      if (++ck == nk) { ck = 0; ++ctl; }
+    }
+  } else {
+    for (int s = 0; s < S; ++s) {
+      wait_step(s);
+      __builtin_amdgcn_s_barrier();
+      if (s > 0) multiply();                         // step s - 1, fragments kept in registers
+      if (ck == 0 && s > 0) { epilogue(ctl - 1); zero_acc(); }
+      int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+      if (s + 2 < S) issue_next(sn);
+      read_frags(smem + st * STAGE);
+      st = st + 1 == NSTAGE ? 0 : st + 1;
+      if (++ck == nk) { ck = 0; ++ctl; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
+    multiply();
   }
+  epilogue(ntl - 1);
 #endif
 }
 
