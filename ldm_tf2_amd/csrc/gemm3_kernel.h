@@ -141,7 +141,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     char* dA = smem + stage * STAGE + wave * 1024;
     char* dB = dA + BM * 128;
     int kb;
-    if constexpr (MODE != 0) {
+    if (p.dbg & 16) {            // timing ablation: no A staging at all (what a halo-staged A would approach)
+      if constexpr (MODE != 0) { const int cc = kt / 9; const int tap = kt - cc * 9; kb = tap * p.Cin * ES + cc * 128; }
+      else kb = kt * 128;
+    } else if constexpr (MODE != 0) {
       const int cc = kt / 9;
       const int tap = kt - cc * 9;
       const int cib = cc * 128;
@@ -204,7 +207,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   }
 
   u32x4 fa[2][TM], fb[2][TN];
+  if (p.dbg & 32) {                                  // defined values for the no-read ablation
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[kg][i] = u32x4{(uint32_t)lane, 1u, 2u, 3u};
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[kg][j] = u32x4{(uint32_t)lane, 5u, 6u, 7u};
+    }
+  }
   auto read_frags = [&](const char* cS) {
+    if (p.dbg & 32) return;                          // timing ablation: no LDS fragment reads
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
 #pragma unroll
@@ -215,9 +228,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   };
   // operands SWAPPED: D[n][m] = sum_k W[n][k] A[m][k]; lane l then holds, for block (i, j),
   // output row m = 16 i + (l & 15) and columns n = 16 j + 4 (l >> 4) + r, r = 0..3
-  auto multiply = [&]() {
+  // prio: the LATE half multiplies at a higher priority than the early half.  Both halves want the
+  // SIMD's matrix pipe in the middle of a period (the early half once its fragment reads are back,
+  // the late half from the barrier on); sharing it evenly makes both finish together and leaves
+  // the late half's fragment reads exposed at the end of the period.
+  auto multiply = [&](int prio) {
     if (p.dbg & 4) return;
-    __builtin_amdgcn_s_setprio(1);
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
@@ -364,7 +382,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   // half's epilogue runs beside the other half's MFMAs.  (Two loops, not one with `late` tests
   // inside: the merged loop keeps the fragments live across the epilogue and spills.)
   auto wait_step = [&](int s) {                      // this wave's LDS-DMAs of step s have landed
-    if (s + 1 < S) {
+    if (s + 1 < S && (p.dbg & 16)) {
+      if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB - 1) : "memory");
+    } else if (s + 1 < S) {
       if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL - 1) : "memory");
     } else {
@@ -379,7 +400,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
       if (s + 2 < S) issue_next(sn);
       read_frags(smem + st * STAGE);
-      multiply();
+      multiply(0);
       st = st + 1 == NSTAGE ? 0 : st + 1;
       if (++ck == nk) { ck = 0; ++ctl; }
     }
@@ -387,7 +408,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     for (int s = 0; s < S; ++s) {
       wait_step(s);
       __builtin_amdgcn_s_barrier();
-      if (s > 0) multiply();                         // step s - 1, fragments kept in registers
+      if (s > 0) multiply(1);                        // step s - 1, fragments kept in registers
       if (ck == 0 && s > 0) { epilogue(ctl - 1); zero_acc(); }
       int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
       if (s + 2 < S) issue_next(sn);
@@ -397,7 +418,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
-    multiply();
+    multiply(1);
   }
   epilogue(ntl - 1);
 #endif

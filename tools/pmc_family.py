@@ -40,7 +40,7 @@ for path in args:
              "dur": collections.defaultdict(float), "cnt": collections.defaultdict(int), "seen": set()}
     if win is None:
       continue
-    f = ("gemm_kernel" if "gemm_kernel<" in n else "attn_kernel" if "attn_kernel" in n else
+    f = ("gemm_kernel" if ("gemm_kernel<" in n or "gemm3_kernel<" in n) else "attn_kernel" if "attn_kernel" in n else
          "groupnorm" if "gn_" in n else "layernorm" if "layernorm" in n else
          "splitk_reduce" if "splitk" in n else "other")
     win["fam"][f][r["Counter_Name"]] += float(r["Counter_Value"])

@@ -27,7 +27,7 @@ def main():
   rows = list(csv.DictReader(open(args.stats_csv)))
   tot = sum(float(r["TotalDurationNs"]) for r in rows)
   evals = sum(int(r["Calls"]) for r in rows if "time_embedding_kernel" in r["Name"])
-  gemm = [r for r in rows if "gemm_kernel<" in r["Name"]]
+  gemm = [r for r in rows if "gemm_kernel<" in r["Name"] or "gemm3_kernel<" in r["Name"]]
   red = [r for r in rows if "splitk_epilogue" in r["Name"]]
   red_ns = sum(float(r["TotalDurationNs"]) for r in red)
   gemm_ns = sum(float(r["TotalDurationNs"]) for r in gemm)
