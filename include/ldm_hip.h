@@ -17,6 +17,16 @@
  *   - dtype: 0 = float32, 1 = bfloat16 (storage; accumulation, statistics,
  *     softmax and the DDIM scheduler are always float32);
  *   - biases / gammas / betas / per-row addends are always float32.
+ *
+ * Why there is no opaque context (no ldm_create / ldm_destroy / *_sync): every entry point is
+ * a pure function of its arguments that only ENQUEUES work on the caller's stream.  The library
+ * owns no device memory (scratch such as the split-K workspace is passed in by the caller, who
+ * therefore decides which stream / model it belongs to), keeps no per-call state (the only
+ * mutable datum is the thread-local last-error string) and never synchronises, so there is
+ * nothing for a handle to hold and nothing for a *_sync to wait on: the caller synchronises its
+ * own stream.  Re-entrancy follows from that: concurrent calls on different streams are safe as
+ * long as they do not share caller-owned scratch.  Environment variables are consulted only by
+ * A/B switches for the tools (read once per process), never for results.
  */
 #ifndef LDM_HIP_H
 #define LDM_HIP_H

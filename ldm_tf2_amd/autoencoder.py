@@ -70,11 +70,17 @@ class _Blocks:
     ops.conv3x3(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
     return out
 
+  # queries per pass of the single-head attention: logits are materialised for one block of queries
+  # at a time, [B, ATTN_QBLOCK, T] f32 (33 MB at B=4, T=4096) instead of [B, T, T] (268 MB)
+  ATTN_QBLOCK = 512
+
   def _attn(self, a, x, out):
-    """autoencoder.py:74-97: single head over all H*W positions, head dim = C.
-    C = 512 is beyond the fused kernel's head sizes, and this block runs once per
-    image, so logits are materialised: q.k^T (batched MFMA GEMM, f32 out) ->
-    row softmax with the C**-0.5 scale -> P.V (batched GEMM against V^T)."""
+    """autoencoder.py:74-97: single head over all H*W positions, head dim = C = 512 -- beyond the
+    fused kernel's head sizes (its per-lane O^T column would need 256 accumulator registers), and
+    the block runs once per image (0.1 % of the decoder's FLOPs).  Per block of ATTN_QBLOCK
+    queries: q.k^T (batched MFMA GEMM, f32 out) -> row softmax with the C**-0.5 scale -> P.V
+    (batched GEMM against V^T).  Rows of a softmax are independent, so blocking the queries
+    changes nothing but the size of the logits scratch."""
     B_, dt = self.buf, self.dtype
     B, h, w, c = x.shape
     T = h * w
@@ -86,12 +92,16 @@ class _Blocks:
     ops.linear(t0, a.q[0], q, bias=a.q[1])
     ops.linear(t0, a.k[0], k, bias=a.k[1])
     ops.bmm_nt(t0.reshape(B, T, c), a.v[0], vt, bias=a.v[1], transposed_out=True)
-    logits = B_.get("at_logits", (B, T, T), torch.float32)
-    ops.bmm_nt(q, k, logits)
-    p = B_.get("at_p", (B, T, T), dt)
-    ops.softmax_rows(logits, p, scale=c ** -0.5)
     o = B_.get("at_o", (B, T, c), dt)
-    ops.bmm_nt(p, vt, o)
+    qb = max(d for d in range(1, min(T, self.ATTN_QBLOCK) + 1) if T % d == 0)   # whole blocks only
+    logits = B_.get("at_logits", (B, qb, T), torch.float32)
+    p = B_.get("at_p", (B, qb, T), dt)
+    for q0 in range(0, T, qb):
+      q1 = min(T, q0 + qb)
+      n = q1 - q0
+      ops.bmm_nt(q[:, q0:q1], k, logits[:, :n])
+      ops.softmax_rows(logits[:, :n], p[:, :n], scale=c ** -0.5)
+      ops.bmm_nt(p[:, :n], vt, o[:, q0:q1])
     ops.linear(o, a.o[0], out, bias=a.o[1], residual=x)
     return out
 

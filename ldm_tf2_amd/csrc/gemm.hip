@@ -315,7 +315,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     cfg = kLnTile;
     split = 1;
   }
-  if (p->out2) {
+  if (p->out2 && cfg < kFirstPersistent) {
     LDM_CHECK_ARG(!p->conv && p->batch == 1 && p->act != LDM_ACT_GEGLU && p->ldc_n == 1 && !p->ln_out && !p->residual,
                   "ldm_gemm: out2 needs plain rows, batch 1, a row-major first output, no GEGLU / ln_out");
     LDM_CHECK_ARG(p->n_split > 0 && p->n_split < p->N && p->n_split % kTiles[cfg].bn == 0,
@@ -330,8 +330,15 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     // persistent ping-pong kernel: bf16 in/out, row-major 16-byte-aligned output, whole n-tiles
     const int bn = kTiles[cfg].bn;
     auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
-    LDM_CHECK_ARG(p->dtype == LDM_BF16 && p->out_dtype == LDM_BF16 && p->batch == 1 && p->ldc_n == 1 && !p->out2 &&
-                      !p->ln_out && split <= 1 && p->N % bn == 0 && p->ldc_m % 8 == 0 && al16(p->out) &&
+    // out2 with n_split == 0: the WHOLE product is stored transposed per group of rows2 rows (V^T)
+    const bool trans = p->out2 != nullptr;
+    if (trans)
+      LDM_CHECK_ARG(p->n_split == 0 && !p->conv && !p->bias && !p->addend && !p->residual && p->act == LDM_ACT_NONE &&
+                        p->rows2 > 0 && p->rows2 % 32 == 0 && p->M % p->rows2 == 0 && p->ld2 % 8 == 0 && p->stride2 % 8 == 0 &&
+                        al16(p->out2),
+                    "ldm_gemm: tile %d transposed output needs n_split 0, a plain product, rows2 %% 32 == 0, ld2 / stride2 %% 8 == 0", cfg);
+    LDM_CHECK_ARG(p->dtype == LDM_BF16 && p->out_dtype == LDM_BF16 && p->batch == 1 && p->ldc_n == 1 &&
+                      !p->ln_out && split <= 1 && p->N % bn == 0 && (trans || (p->ldc_m % 8 == 0 && al16(p->out))) &&
                       (!p->residual || (p->ldr % 4 == 0 && al16(p->residual))) && (!p->bias || al16(p->bias)) &&
                       (!p->addend || (al16(p->addend) && p->add_ld % 4 == 0)),
                   "ldm_gemm: tile %d (persistent) needs bf16 in/out, batch 1, a row-major 16-byte-aligned output, "
@@ -359,7 +366,8 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     g.nsplit = cdiv(g.ntiles, g.tiles_per_wg);
     dim3 grid3((unsigned)(g.panels * g.nsplit));
     hipStream_t s3 = (hipStream_t)stream;
-    const int epi = epi_code(p->bias != nullptr, p->addend != nullptr, p->residual != nullptr, p->act);
+    g.out_t = (char*)p->out2; g.ld_t = p->ld2; g.stride_t = p->stride2; g.rows_t = p->rows2;
+    const int epi = trans ? kEpiTrans : epi_code(p->bias != nullptr, p->addend != nullptr, p->residual != nullptr, p->act);
     bool ok;
     if (!p->conv) ok = launch_gemm3<0>(bn / 32, epi, g, grid3, s3);
     else if (!p->upsample) ok = launch_gemm3<1>(bn / 32, epi, g, grid3, s3);

@@ -35,6 +35,11 @@ bool launch_gemm3<0>(int tn, int epi, const Gemm3Args& a, dim3 grid, hipStream_t
     else hipLaunchKernelGGL((gemm3_kernel<4, 0, epi_code(true, false, false, 3)>), grid, dim3(512), 0, s, a);
     return true;
   }
+  if (epi == kEpiTrans) {
+    if (tn == 5) hipLaunchKernelGGL((gemm3_kernel<5, 0, kEpiTrans>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((gemm3_kernel<4, 0, kEpiTrans>), grid, dim3(512), 0, s, a);
+    return true;
+  }
   return false;
 }
 }  // namespace ldm_gemm_detail

@@ -41,13 +41,18 @@ struct Gemm3Args {
   int ntiles;         // N / BN
   int nsplit;         // workgroups per panel
   int tiles_per_wg;   // ceil(ntiles / nsplit)
+  char* out_t;        // transposed output (EPI bit 5): out_t[(m / rows_t) * stride_t + n * ld_t + m % rows_t]
+  int64_t ld_t, stride_t;
+  int rows_t;
   int dbg;            // timing ablations (LDM_G3_DEBUG): 1 = no stores, 2 = no epilogue, 4 = no MFMA, 8 = no staging
 };
 
 // Epilogue variant, a compile-time constant: a runtime "is there a bias / residual" test around
 // each epilogue load makes the compiler branch and drain the memory pipeline per load.
 //   bit 0 bias, bit 1 per-group addend, bit 2 residual, bits 3-4 activation (LDM_ACT_* code)
-constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4;
+//   bit 5 TRANSPOSED store per group of rows_t rows (the V projection lands directly in the
+//         attention kernel's V^T [sample][head dim][token]); plain product only
+constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4, kEpiTrans = 32;
 constexpr int epi_code(bool bias, bool add, bool res, int act) { return (bias ? 1 : 0) | (add ? 2 : 0) | (res ? 4 : 0) | (act << 3); }
 
 // BN = 32 * TN columns per n-tile; waves 4 (M) x 2 (N); wave tile 64 x (16 TN)
@@ -241,9 +246,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[kg][j]),
-                                                              __builtin_bit_cast(bf16x8, fa[kg][i]), acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          if constexpr ((EPI & kEpiTrans) != 0)       // natural order: lane = column n, registers = 4 rows m
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[kg][i]),
+                                                                __builtin_bit_cast(bf16x8, fb[kg][j]), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[kg][j]),
+                                                                __builtin_bit_cast(bf16x8, fa[kg][i]), acc[i][j], 0, 0, 0);
+        }
     __builtin_amdgcn_s_setprio(0);
   };
 
@@ -256,6 +266,36 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     if (p.dbg & 2) return;
     const int n_w = (nt_begin + tl) * BN + wn * WTN;          // first column of this wave's tile
     const int g = lh;
+    if constexpr ((EPI & kEpiTrans) != 0) {
+      // Transposed store: the lane owns column n = n_w + 16 j + (l & 15) and rows 16 i + 4 g + r.  Two
+      // row blocks (i, i+1) are exchanged with v_permlane16_swap (8 consecutive rows = 16 bytes per
+      // lane), then moved so that the four pieces of 32 consecutive rows of ONE column sit in adjacent
+      // lanes: every lane quad writes 64 contiguous bytes of out_t[sample][n][token].
+      const int col2 = lane >> 2, pc = lane & 3;
+      const int src = (16 * ((pc >> 1) | ((pc & 1) << 1)) + col2) * 4;
+#pragma unroll
+      for (int ip = 0; ip < TM; ip += 2) {
+        const int mrow = m0 + wm * WTM + 16 * ip + 8 * pc;      // first of this lane's 8 rows (after the move)
+        const bool valid = mrow < p.M && !(p.dbg & 1);
+        const int mc = valid ? mrow : 0;
+        const int smp = mc / p.rows_t, tok = mc - smp * p.rows_t;
+        bf16_t* obase = (bf16_t*)p.out_t + (int64_t)smp * p.stride_t + tok;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const uint32_t x0 = pack_bf2(acc[ip][j][0], acc[ip][j][1]), x1 = pack_bf2(acc[ip][j][2], acc[ip][j][3]);
+          const uint32_t y0 = pack_bf2(acc[ip + 1][j][0], acc[ip + 1][j][1]), y1 = pack_bf2(acc[ip + 1][j][2], acc[ip + 1][j][3]);
+          const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+          u32x4 o;
+          o[0] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s0[0]);
+          o[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s1[0]);
+          o[2] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s0[1]);
+          o[3] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s1[1]);
+          if (valid) *(u32x4*)(obase + (int64_t)(n_w + 16 * j + col2) * p.ld_t) = o;
+        }
+      }
+      return;
+    }
     // All global loads of the epilogue are issued in batches ahead of their use (beside LDS-DMAs
     // the compiler waits vmcnt(0) at the first use of an ordinary load).
     f32x4 bv[TN];                                            // bias of this lane's 4 columns per block

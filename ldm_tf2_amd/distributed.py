@@ -25,11 +25,14 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     if backend is None:
-      backend = "nccl" if torch.cuda.is_available() else "gloo"
+      # LDM_DIST_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks
+      backend = os.environ.get("LDM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("LDM_ONE_DEVICE"):
+      local = 0                               # rehearsal: every rank on device 0
     if backend == "nccl":
       torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
-  return rank, world, local
+  return rank, world, (0 if os.environ.get("LDM_ONE_DEVICE") else local)
 
 
 def shard_range(rank, batch_per_rank):
@@ -46,6 +49,11 @@ def all_gather_images(images):
   images = images.contiguous()
   out = torch.empty((dist.get_world_size() * images.shape[0],) + tuple(images.shape[1:]),
                     dtype=images.dtype, device=images.device)
+  if images.is_cuda and dist.get_backend() == "gloo":   # rehearsal only: gloo gathers host tensors
+    host = torch.empty(out.shape, dtype=out.dtype)
+    dist.all_gather_into_tensor(host, images.cpu())
+    out.copy_(host)
+    return out
   dist.all_gather_into_tensor(out, images)
   return out
 
@@ -58,6 +66,8 @@ def barrier():
 def max_over_ranks(value: float, device) -> float:
   if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
     return float(value)
+  if dist.get_backend() == "gloo":
+    device = "cpu"
   t = torch.tensor([float(value)], dtype=torch.float64, device=device)
   dist.all_reduce(t, op=dist.ReduceOp.MAX)
   return float(t.item())
@@ -77,6 +87,8 @@ def gather_floats(value: float, device):
   """One float per rank, in rank order, on every rank (bench.py: per-rank loop times)."""
   if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
     return [float(value)]
+  if dist.get_backend() == "gloo":
+    device = "cpu"
   t = torch.tensor([float(value)], dtype=torch.float64, device=device)
   out = torch.empty(dist.get_world_size(), dtype=torch.float64, device=device)
   dist.all_gather_into_tensor(out, t)

@@ -136,8 +136,11 @@ _PERSISTENT_TILES = (13, 14)
 
 
 def plan_key(p) -> str:
-  return "M%d N%d K%d b%d conv%d H%d W%d s%d u%d nlp%d act%d dt%d odt%d" % (
+  key = "M%d N%d K%d b%d conv%d H%d W%d s%d u%d nlp%d act%d dt%d odt%d" % (
       p.M, p.N, p.K, p.batch, p.conv, p.H, p.W, p.stride, p.upsample, p.no_lead_pad, p.act, p.dtype, p.out_dtype)
+  if p.out2 and p.n_split == 0:
+    key += " t1"            # whole product stored transposed (linear_t)
+  return key
 
 
 def _cfg_key(rows, latent, dtype):
@@ -334,6 +337,43 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
     p.ln_gamma, p.ln_beta = _ptr(_f32(gamma, "ln gamma")), _ptr(_f32(beta, "ln beta"))
   _gemm(p, x.device)
   return out
+
+
+def linear_t_supported(x, wt, out_t):
+  """True if `linear_t` can run this product (persistent kernel: bf16, N a multiple of 128 or 160,
+  groups of rows that are multiples of 32)."""
+  K, N = x.shape[-1], wt.shape[0]
+  M = x.numel() // K
+  G = out_t.shape[0]
+  return (x.dtype == torch.bfloat16 and out_t.dtype == torch.bfloat16 and K % 64 == 0 and
+          (N % 128 == 0 or N % 160 == 0) and M % G == 0 and (M // G) % 32 == 0 and out_t.stride(2) == 1 and
+          out_t.stride(1) % 8 == 0 and out_t.stride(0) % 8 == 0)
+
+
+def linear_t(x, wt, out_t, tile=0):
+  """out_t[g, n, t] = sum_k x[g * T + t, k] * wt[n, k] with T = M / G: the product stored
+  TRANSPOSED per group of T rows (the self-attention V projection lands directly in the attention
+  kernel's V^T [rows, heads*Sp, T]).  Runs on the persistent kernel (tile 13 / 14; the plan table
+  may name which)."""
+  K = x.shape[-1]
+  N = wt.shape[0]
+  M = x.numel() // K
+  G = out_t.shape[0]
+  assert wt.shape[1] == K and wt.is_contiguous() and wt.dtype == x.dtype
+  assert out_t.dim() == 3 and out_t.shape[1] == N and out_t.shape[2] >= M // G
+  p = GemmParams()
+  p.a, p.w = _ptr(x), _ptr(wt)
+  p.out = p.out2 = _ptr(out_t)
+  p.lda, p.ldc_m, p.ldc_n = row_ld(x), N, 1
+  p.M, p.N, p.K, p.batch = M, N, K, 1
+  p.act, p.dtype, p.out_dtype, p.alpha = ACT_NONE, code(x.dtype), code(out_t.dtype), 1.0
+  p.n_split, p.rows2, p.ld2, p.stride2 = 0, M // G, out_t.stride(1), out_t.stride(0)
+  p.tile = tile
+  resolve_plan(p)
+  if p.tile not in _PERSISTENT_TILES:
+    p.tile, p.split_k = (14 if N % 128 == 0 else 13), 0
+  _gemm(p, x.device)
+  return out_t
 
 
 def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale, a_shift,

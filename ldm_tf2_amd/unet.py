@@ -106,6 +106,8 @@ class UNet:
     # fuse_qkv: the self-attention q|k and v projections as one GEMM launch with a transposed second
     # output (ldm_gemm out2); LDM_NO_FUSED_QKV=1 is the A/B switch
     self._fuse_qkv = bool(fuse_qkv) and os.environ.get("LDM_NO_FUSED_QKV") is None
+    # bf16: q|k and v as two persistent-kernel launches (v stored transposed); LDM_NO_SPLIT_QKV=1: A/B switch
+    self._split_qkv = dtype == torch.bfloat16 and os.environ.get("LDM_NO_SPLIT_QKV") is None
     self._fuse_cache = {}
     self._model_channels = model_channels
     self._out_channels = out_channels
@@ -260,7 +262,12 @@ class UNet:
     qk = B_.get("st_qk", (R, T, 2 * hs), dt)
     tp = (T + 7) // 8 * 8
     vt = B_.get("st_vt", (R, hs, tp), dt, zero=True)
-    if self._fuse_qkv and T % 4 == 0:
+    if self._split_qkv and ops.linear_t_supported(ln, st.v1, vt):
+      # bf16: q|k row-major and v TRANSPOSED (straight into the attention kernel's V^T layout) as two
+      # launches that can both take the persistent kernel (ops.linear_t)
+      ops.linear(ln, st.qk1, qk)
+      ops.linear_t(ln, st.v1, vt)
+    elif self._fuse_qkv and T % 4 == 0:
       # q | k | v in ONE launch: q|k row-major, v straight into the attention kernel's V^T layout
       ops.linear(ln, st.qkv1, qk, out2=vt)
     else:

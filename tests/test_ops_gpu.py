@@ -581,3 +581,23 @@ def test_persistent_conv3x3(dev, cfg):
                   tile=tile, split_k=-nsplit)
         ref = base + (0 if ad is None else ad[:, None, None, :]) + (0 if rs is None else rs.float())
         close(out, ref, dtype)
+
+
+@pytest.mark.parametrize("R,T,K,N", [(3, 64, 320, 384), (2, 1024, 320, 384), (4, 256, 640, 640), (2, 96, 128, 160)])
+def test_persistent_linear_transposed(dev, R, T, K, N):
+  """ops.linear_t: the product stored transposed per group of T rows (V^T of the self-attention)."""
+  o = ops()
+  dtype = torch.bfloat16
+  x = rnd((R, T, K), dtype, 1)
+  w = rnd((N, K), dtype, 2, K ** -0.5)
+  tp = (T + 7) // 8 * 8 + 8                       # a padded row pitch, as the attention V^T buffers have
+  out = torch.full((R, N, tp), 3.0, dtype=dtype, device=dev)
+  assert o.linear_t_supported(x.to(dev), w.to(dev), out)
+  o.linear_t(x.to(dev), w.to(dev), out)
+  ref = torch.einsum("rtk,nk->rnt", x.float(), w.float())
+  close(out[:, :, :T], ref, dtype)
+  assert bool((out[:, :, T:] == 3.0).all())     # the pad columns are not touched
+  # same result as the batched transposed-output GEMM the non-persistent path uses
+  out2 = torch.zeros(R, N, tp, dtype=dtype, device=dev)
+  o.bmm_nt(x.to(dev), w.to(dev), out2, transposed_out=True)
+  close(out[:, :, :T], out2[:, :, :T].cpu(), dtype)
