@@ -68,11 +68,16 @@ for path in args:
   totals.setdefault("_launches_per_eval", {}).update({f: cnt[f] / max(evals, 1) for f in cnt})
 
 if out_json:
-  g = totals.get("gemm_kernel", {})
+  # the family bench.py's roofline names = every launch ldm_gemm makes: the GEMM / conv kernels AND
+  # their split-K reduce launches
+  g = dict(totals.get("gemm_kernel", {}))
+  for c, v in totals.get("splitk_reduce", {}).items():
+    g[c] = g.get(c, 0.0) + v
   res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; "
-                   "family = gemm_kernel<...>; per U-Net evaluation (dispatches between time_embedding_kernel and cfg_ddim_kernel only)",
+                   "family = gemm_kernel<...> + gemm3_kernel<...> + splitk_epilogue*; per U-Net evaluation (dispatches between time_embedding_kernel and cfg_ddim_kernel only)",
          "fetch_kb_raw_per_eval": g.get("FETCH_SIZE"), "write_kb_raw_per_eval": g.get("WRITE_SIZE"),
-         "launches_per_eval": totals.get("_launches_per_eval", {}).get("gemm_kernel")}
+         "launches_per_eval": (totals.get("_launches_per_eval", {}).get("gemm_kernel", 0) +
+                               totals.get("_launches_per_eval", {}).get("splitk_reduce", 0))}
   if g.get("FETCH_SIZE") is not None and g.get("WRITE_SIZE") is not None:
     res["hbm_read_bytes_per_eval"] = g["FETCH_SIZE"] * 1024.0 * 2.0     # gfx950 correction
     res["hbm_write_bytes_per_eval"] = g["WRITE_SIZE"] * 1024.0
