@@ -75,12 +75,12 @@ class _Blocks:
   ATTN_QBLOCK = 512
 
   def _attn(self, a, x, out):
-    """autoencoder.py:74-97: single head over all H*W positions, head dim = C = 512 -- beyond the
-    fused kernel's head sizes (its per-lane O^T column would need 256 accumulator registers), and
-    the block runs once per image (0.1 % of the decoder's FLOPs).  Per block of ATTN_QBLOCK
-    queries: q.k^T (batched MFMA GEMM, f32 out) -> row softmax with the C**-0.5 scale -> P.V
-    (batched GEMM against V^T).  Rows of a softmax are independent, so blocking the queries
-    changes nothing but the size of the logits scratch."""
+    """autoencoder.py:74-97: single head over all H*W positions, head dim = C.  C = 512 (every real
+    configuration) runs the fused wide-head attention kernel (attention.hip: attn_wide_kernel).
+    Other widths (the tiny test configurations) fall back to q.k^T (batched MFMA GEMM, f32 out) ->
+    row softmax with the C**-0.5 scale -> P.V (batched GEMM against V^T), ATTN_QBLOCK queries at
+    a time: rows of a softmax are independent, so blocking the queries changes nothing but the
+    size of the logits scratch."""
     B_, dt = self.buf, self.dtype
     B, h, w, c = x.shape
     T = h * w
@@ -93,6 +93,13 @@ class _Blocks:
     ops.linear(t0, a.k[0], k, bias=a.k[1])
     ops.bmm_nt(t0.reshape(B, T, c), a.v[0], vt, bias=a.v[1], transposed_out=True)
     o = B_.get("at_o", (B, T, c), dt)
+    if c == 512:
+      # the real configurations (KL-f8 / VQ-f8 mid block and VQ level-3 blocks: C = 512): fused
+      # flash-style kernel with the head dim split over the four waves of a workgroup -- logits
+      # never leave the chip
+      ops.attention(q, k, vt, o, 1, 512, c ** -0.5)
+      ops.linear(o, a.o[0], out, bias=a.o[1], residual=x)
+      return out
     qb = max(d for d in range(1, min(T, self.ATTN_QBLOCK) + 1) if T % d == 0)   # whole blocks only
     logits = B_.get("at_logits", (B, qb, T), torch.float32)
     p = B_.get("at_p", (B, qb, T), dt)

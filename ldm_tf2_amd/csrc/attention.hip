@@ -255,6 +255,196 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
   }
 }
 
+
+// ---- wide heads (SP = 512: the autoencoder's single-head attention, autoencoder.py:74-97) ----------
+// A lane-owned O^T column of 512 dims would need 256 accumulator registers, so the head dim is
+// SPLIT over the 4 waves of a workgroup: all four waves serve the SAME 32 queries, wave w owns dims
+// [128 w, 128 w + 128).  Per 32-key tile: each wave forms the partial logits of its slice
+// (S_w^T = K[:, slice] . Q[:, slice]^T), the four partials are summed through LDS in wave order (so every
+// wave holds the identical full S^T), the online softmax runs redundantly per wave (lane-local, as
+// above), and each wave accumulates its own 128 rows of O^T = V^T . P^T.  Logits never leave the chip
+// (the GEMM + softmax + GEMM path materialised [B, T, T] floats: 268 MB at B = 4, T = 4096).
+// This block runs once per image (0.1 % of the decoder's FLOPs): staging is the simple
+// load -> barrier -> compute form, not pipelined.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_wide_kernel(AttnArgs p) {
+  using TR = AttnTraits<T>;
+  constexpr int EPC = Elem<T>::kPerChunk;
+  constexpr int NPC = TR::NPC;
+  constexpr int SP = 512, SPW = 128, KT = 32;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int DCH = SP / EPC;                    // 16-byte chunks per K row
+  constexpr int VCH = KT / EPC;                    // 16-byte chunks per V^T row
+  constexpr int NKGW = SPW * ES / 32;              // 32-byte k groups over this wave's slice
+  constexpr int NDW = SPW / 32;                    // O^T tiles of this wave
+  constexpr int KRS = SP * ES + 16;                // padded LDS row strides (odd * 16 B)
+  constexpr int VRS = KT * ES + 16;
+  constexpr int CK = KT * DCH / 256;               // staging chunks per thread
+  constexpr int CV = SP * VCH / 256;
+  static_assert((KT * DCH) % 256 == 0 && (SP * VCH) % 256 == 0, "staging");
+  extern __shared__ __attribute__((aligned(16))) char smem_w[];
+  char* sK = smem_w;
+  char* sV = sK + KT * KRS;
+  float* sX = (float*)(sV + SP * VRS);             // [4 waves][64 lanes][16] partial logits
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * 32;
+  const T* Q = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)head * SP;
+  const T* Kp = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)head * SP;
+  const T* Vt = (const T*)p.vt + (int64_t)b * p.vt_bs + (int64_t)head * SP * p.ldvt;
+
+  u32x4 qf[NKGW];                                  // this wave's slice of the query rows (B operand)
+  {
+    const int qi = min(q0 + lr, p.Tq - 1);
+    const T* qr = Q + (int64_t)qi * p.ldq + wave * SPW;
+#pragma unroll
+    for (int g = 0; g < NKGW; ++g) qf[g] = *(const u32x4*)(qr + (2 * g + lh) * EPC);
+  }
+  f32x16 o[NDW];
+#pragma unroll
+  for (int d = 0; d < NDW; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c2 = p.scale * 1.4426950408889634f;
+  const int krow = TR::kappa(lr);
+  const int ntiles = (p.Tk + KT - 1) / KT;
+  for (int t = 0; t < ntiles; ++t) {
+    const int kt0 = t * KT;
+    __syncthreads();                               // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < CK; ++i) {
+      const int id = tid + i * 256;
+      const int key = id / DCH, dc = id - key * DCH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kt0 + key < p.Tk) v = *(const u32x4*)(Kp + (int64_t)(kt0 + key) * p.ldk + dc * EPC);
+      *(u32x4*)(sK + key * KRS + dc * 16) = v;
+    }
+#pragma unroll
+    for (int i = 0; i < CV; ++i) {
+      const int id = tid + i * 256;
+      const int dim = id / VCH, kc = id - dim * VCH;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (kt0 + kc * EPC < p.ldvt) v = *(const u32x4*)(Vt + (int64_t)dim * p.ldvt + kt0 + kc * EPC);
+      *(u32x4*)(sV + dim * VRS + kc * 16) = v;
+    }
+    __syncthreads();
+    // partial logits of this wave's 128 dims
+    f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = 0.f;
+    {
+      const char* kr = sK + krow * KRS + wave * SPW * ES + lh * 16;
+#pragma unroll
+      for (int g = 0; g < NKGW; ++g) {
+        const u32x4 kf = *(const u32x4*)(kr + g * 32);
+        mma32a(s, kf, qf[g], T());
+      }
+    }
+    // sum of the four partials, in wave order (identical in every wave)
+    {
+      float* mine = sX + (wave * 64 + lane) * 16;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 v = {s[4 * r4], s[4 * r4 + 1], s[4 * r4 + 2], s[4 * r4 + 3]};
+        *(f32x4*)(mine + 4 * r4) = v;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float* src = sX + (w * 64 + lane) * 16;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 v = *(const f32x4*)(src + 4 * r4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[4 * r4 + e] += v[e];
+        }
+      }
+    }
+    if (kt0 + KT > p.Tk) {   // wave-uniform
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + TR::kappa((r & 3) + 8 * (r >> 2) + 4 * lh);
+        if (key >= p.Tk) s[r] = -INFINITY;
+      }
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c2;
+    if (!__all(mt <= m_run + 8.0f)) {
+      const float m_new = fmaxf(m_run, mt);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < NDW; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+    }
+    float ls = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -m_run));
+      s[r] = e;
+      ls += e;
+    }
+    l_run += ls;
+    // O^T[slice] += V^T[slice] . P^T
+#pragma unroll
+    for (int pc = 0; pc < NPC; ++pc) {
+      const u32x4 pf = TR::pchunk(s, pc);
+      const int coff = (2 * pc + lh) * 16;
+#pragma unroll
+      for (int d = 0; d < NDW; ++d) {
+        const u32x4 vf = *(const u32x4*)(sV + (wave * SPW + d * 32 + lr) * VRS + coff);
+        mma32a(o[d], vf, pf, T());
+      }
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qi = q0 + lr;
+  if (qi < p.Tq) {
+    T* orow = (T*)p.out + (int64_t)b * p.o_bs + (int64_t)qi * p.ldo + (int64_t)head * SP + wave * SPW;
+#pragma unroll
+    for (int d = 0; d < NDW; ++d)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dim = d * 32 + 8 * r4 + 4 * lh;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = o[d][r4 * 4 + e] * inv;
+        if constexpr (sizeof(T) == 2) {
+          u32x2 pk; pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
+          *(u32x2*)(orow + dim) = pk;
+        } else {
+          f32x4 pk = {v[0], v[1], v[2], v[3]};
+          *(f32x4*)(orow + dim) = pk;
+        }
+      }
+  }
+}
+
+template <typename T>
+int launch_attn_wide(const AttnArgs& a, int batch, hipStream_t s) {
+  constexpr int ES = (int)sizeof(T);
+  const int lds = 32 * (512 * ES + 16) + 512 * (32 * ES + 16) + 4 * 64 * 16 * 4;
+  static bool attr_set = false;      // per element type (template instance)
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)attn_wide_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return -1;
+    attr_set = true;
+  }
+  dim3 grid((a.Tq + 31) / 32, a.heads, batch);
+  hipLaunchKernelGGL((attn_wide_kernel<T>), grid, dim3(256), lds, s, a);
+  return 0;
+}
+
 template <typename T>
 int launch_attn(const AttnArgs& a, int Sp, dim3 grid, hipStream_t s) {
   // keys per tile: 128 for bf16 heads <= 64 (half the barriers), 64 above (register budget);
@@ -300,7 +490,9 @@ extern "C" int ldm_attention(const void* q, int64_t ldq, int64_t q_bs, const voi
   a.ldo = ldo; a.o_bs = o_bs; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.scale = scale;
   dim3 grid((Tq + 127) / 128, heads, batch);
   hipStream_t s = (hipStream_t)stream;
-  int r = dtype == LDM_BF16 ? launch_attn<bf16_t>(a, Sp, grid, s) : launch_attn<float>(a, Sp, grid, s);
-  LDM_CHECK_ARG(r == 0, "ldm_attention: unsupported padded head size Sp=%d (32/48/64/80/96/160)", Sp);
+  int r;
+  if (Sp == 512) r = dtype == LDM_BF16 ? launch_attn_wide<bf16_t>(a, batch, s) : launch_attn_wide<float>(a, batch, s);
+  else r = dtype == LDM_BF16 ? launch_attn<bf16_t>(a, Sp, grid, s) : launch_attn<float>(a, Sp, grid, s);
+  LDM_CHECK_ARG(r == 0, "ldm_attention: unsupported padded head size Sp=%d (32/48/64/80/96/160, or 512 = head dim split over 4 waves)", Sp);
   return ldm_launch_status("ldm_attention");
 }

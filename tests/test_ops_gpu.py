@@ -601,3 +601,25 @@ def test_persistent_linear_transposed(dev, R, T, K, N):
   out2 = torch.zeros(R, N, tp, dtype=dtype, device=dev)
   o.bmm_nt(x.to(dev), w.to(dev), out2, transposed_out=True)
   close(out[:, :, :T], out2[:, :, :T].cpu(), dtype)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("B,T", [(2, 64), (1, 1024), (3, 96), (1, 200)])
+def test_attention_wide_head(dev, dtype, B, T):
+  """Single-head attention with head dim 512 (autoencoder.py:74-97): the head dim is split over the
+  four waves of a workgroup; ragged key counts are masked in the last tile; a spiked key forces the
+  lazy-rescale branch."""
+  o = ops()
+  C = 512
+  q = rnd((B, T, C), dtype, 1) * 0.7
+  k = rnd((B, T, C), dtype, 2) * 0.7
+  v = rnd((B, T, C), dtype, 3)
+  k[0, T // 2] = q[0, 5] * 6.0                       # one key that dominates query 5 late in the sweep
+  scale = C ** -0.5
+  ref = torch.softmax(torch.einsum("bqc,bkc->bqk", q.float(), k.float()) * scale, -1) @ v.float()
+  ldvt = (T + 7) // 8 * 8
+  vt = torch.zeros(B, C, ldvt, dtype=dtype)
+  vt[:, :, :T] = v.transpose(1, 2)
+  out = torch.zeros(B, T, C, dtype=dtype, device=dev)
+  o.attention(q.to(dev), k.to(dev), vt.to(dev), out, 1, 512, scale)
+  close(out, ref, dtype, scale=2.0)
