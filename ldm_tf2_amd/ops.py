@@ -257,10 +257,8 @@ def plan_candidates(M, N, K, batch, act, dtype):
 
 
 def _load_default_plans():
-  if os.environ.get("LDM_NO_PLANS") is not None:
-    return
   d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "plans")
-  if os.path.isdir(d):
+  if os.path.isdir(d) and os.environ.get("LDM_NO_PLANS") is None:
     for name in sorted(os.listdir(d)):
       if name.endswith(".json"):
         load_plans(os.path.join(d, name))

@@ -34,6 +34,8 @@ def main():
   ap.add_argument("--budget-s", type=float, default=420.0)
   ap.add_argument("--min-gain-us", type=float, default=4.0)
   ap.add_argument("--keep-plans", action="store_true", help="start from the loaded plan table (refinement pass)")
+  ap.add_argument("--tiles", default="", help="only candidates on these tiles (comma list), e.g. a refinement pass for new tiles")
+  ap.add_argument("--max-m", type=int, default=0, help="only problems with M <= this")
   args = ap.parse_args()
   dev = torch.device("cuda:0")
   dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -94,9 +96,14 @@ def main():
     if time.time() - t_start > args.budget_s:
       print("time budget reached", flush=True)
       break
+    if args.max_m and M > args.max_m:
+      continue
     start = ops.gemm_plans().get(key)
     best_c, best_ms = start, cur
+    only = {int(t) for t in args.tiles.split(",")} if args.tiles else None
     for cand in ops.plan_candidates(M, N, K, batch, act, dtype):
+      if only is not None and cand[0] not in only:
+        continue
       ops.set_plan(key, cand)
       try:
         ms = step_ms()
@@ -105,6 +112,18 @@ def main():
         continue
       if ms < best_ms - args.min_gain_us * 1e-3:
         best_c, best_ms = cand, ms
+    if best_c != start:
+      # confirm against a fresh timing of the starting plan: clocks drift by 1-2 % over a tuning
+      # run, and a candidate timed in a fast minute must not win on that alone
+      ops.set_plan(key, start)
+      ms_start = step_ms()
+      ops.set_plan(key, best_c)
+      ms_best = step_ms()
+      if ms_best < ms_start - args.min_gain_us * 1e-3:
+        best_ms = ms_best
+      else:
+        print(f"   {key}: {best_c} not confirmed ({ms_start:.3f} vs {ms_best:.3f} ms)", flush=True)
+        best_c, best_ms = start, ms_start
     ops.set_plan(key, best_c)
     if best_c is not None and best_c != start:
       plans[key] = list(best_c)
