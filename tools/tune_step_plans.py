@@ -104,6 +104,8 @@ def main():
     for cand in ops.plan_candidates(M, N, K, batch, act, dtype):
       if only is not None and cand[0] not in only:
         continue
+      if key.endswith(" t1") and cand[0] not in (13, 14):     # whole-product-transposed launches: persistent kernel only
+        continue
       ops.set_plan(key, cand)
       try:
         ms = step_ms()
