@@ -114,6 +114,9 @@ def test_every_packaged_plan_matches_the_oracle(dev, key, plan):
 # ---- full-size U-Net at the bench batch shapes ---------------------------------------------------
 UNET = dict(model_channels=320, out_channels=4, num_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8)
 KL = dict(latent_channels=4, channels=128, num_blocks=2, multipliers=(1, 2, 4, 4))
+TXT = dict(vocab_size=30522, encoder_stack_size=32, hidden_size=1280, num_heads=8, size_per_head=64,
+           filter_size=5120, max_seq_len=77)
+LDM = dict(num_steps=1000, beta_start=0.00085, beta_end=0.012, scale_factor=0.18215, eta=0.)
 
 
 def _rel(got, ref):
@@ -176,3 +179,37 @@ def test_fullsize_decode_b4_latent64(dev):
     assert r < REL[dtype]
     del ae
     torch.cuda.empty_cache()
+
+
+def test_c3_loop_reproducible_bf16(dev, unet_w):
+  """The benchmarked loop itself (BASELINE configs[2] shape: B=16, bf16, CFG 5, captured step graph,
+  packaged plan table, persistent / ping-pong / split-K launches) at 6 DDIM steps: two passes are
+  bit-identical, the eager (uncaptured) loop gives the same bits, and a sampler with ANOTHER prompt
+  in between does not disturb it -- a race in a hand-scheduled kernel shows up here as a flipped bit."""
+  from ldm_tf2_amd.autoencoder import AutoencoderKL
+  from ldm_tf2_amd.model_runners import LatentDiffusionModelSampler
+  from ldm_tf2_amd.transformer import TransformerModel
+  from ldm_tf2_amd.unet import UNet
+  dt = torch.bfloat16
+  small_txt = dict(TXT, encoder_stack_size=2)
+  wt = Wt.init_weights(Wt.transformer_manifest(**small_txt), seed=2, scope="cond_stage_model")
+  kl_w = Wt.init_weights(Wt.decoder_manifest(**KL), seed=2, mode="random", scope="autoencoder")
+  unet = UNet(**UNET, weights=unet_w, dtype=dt, device=dev)
+  ae = AutoencoderKL(**KL, weights=kl_w, dtype=dt, device=dev)
+  txt = TransformerModel(**small_txt, weights=wt, dtype=dt, device=dev)
+  B = 16
+
+  def ids(seed):
+    cond = np.random.default_rng(seed).integers(0, 30522, size=(B, 77))
+    return np.concatenate([np.tile([[101, 102] + [0] * 75], (B, 1)), cond], 0)
+
+  s = LatentDiffusionModelSampler(unet, ae, txt, verbose=False, use_graph=True, num_ddim_steps=6, **LDM)
+  a = s.ddim_p_sample_loop(ids(1), [B, 32, 32, 4], 5., seed=3).clone()
+  assert tuple(a.shape) == (B, 256, 256, 3) and bool(torch.isfinite(a.float()).all())
+  other = s.ddim_p_sample_loop(ids(2), [B, 32, 32, 4], 5., seed=3).clone()
+  assert not torch.equal(a, other)
+  b = s.ddim_p_sample_loop(ids(1), [B, 32, 32, 4], 5., seed=3).clone()
+  assert torch.equal(a, b)
+  e = LatentDiffusionModelSampler(unet, ae, txt, verbose=False, use_graph=False, num_ddim_steps=6, **LDM)
+  c = e.ddim_p_sample_loop(ids(1), [B, 32, 32, 4], 5., seed=3)
+  assert torch.equal(a, c)
