@@ -34,10 +34,6 @@ def code(dtype) -> int:
     raise TypeError(f"unsupported dtype {dtype}: the HIP path stores float32 or bfloat16")
 
 
-def torch_dtype(c: int):
-  return torch.float32 if c == F32 else torch.bfloat16
-
-
 def _stream():
   return torch.cuda.current_stream().cuda_stream
 

@@ -175,8 +175,10 @@ class UNet:
     self.gn_out = (L.vec(w["groupnorm/gamma"], dev), L.vec(w["groupnorm/beta"], dev))
     self.conv_out = (L.vec(w["conv_out/kernel"], dev), L.vec(w["conv_out/bias"], dev))
     # bf16: the 320 -> 4 output conv as an implicit-GEMM launch too (N = 4 of a 64-column tile is
-    # wasted MFMA work, but 3 GFLOP on the matrix cores beat the 8-lanes-per-pixel FMA kernel 4x)
-    self.conv_out_mm = L.conv_kernel(w["conv_out/kernel"], dt, dev) if dt == torch.bfloat16 else None
+    # wasted MFMA work, but 3 GFLOP on the matrix cores beat the 8-lanes-per-pixel FMA kernel 4x);
+    # LDM_SMALL_CONV_OUT=1: the scalar kernel (A/B switch)
+    self.conv_out_mm = (L.conv_kernel(w["conv_out/kernel"], dt, dev)
+                        if dt == torch.bfloat16 and os.environ.get("LDM_SMALL_CONV_OUT") is None else None)
     # all ResBlock temb projections as ONE skinny Dense [sum(Cout), 4*mc]
     off, ks, bs = 0, [], []
     for r in res_all:
@@ -379,7 +381,7 @@ class UNet:
     ops.groupnorm(final, self.gn_out[0], self.gn_out[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
     if out is None:
       out = torch.empty(R, h, w, self._out_channels, dtype=f32, device=self.device)
-    if self.conv_out_mm is not None and os.environ.get("LDM_SMALL_CONV_OUT") is None:
+    if self.conv_out_mm is not None:
       ops.conv3x3(t0, self.conv_out_mm, out, bias=self.conv_out[1])
     else:
       ops.conv3x3_small(t0, self.conv_out[0], self.conv_out[1], out)
