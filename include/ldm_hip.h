@@ -108,7 +108,7 @@ typedef struct {
   int32_t dtype;         /* of a, w */
   int32_t out_dtype;     /* of out, residual */
   int32_t split_k;       /* 0 = let the library choose */
-  int32_t tile;          /* 0 = auto; 1-14 force an implicit-GEMM tile (9-12: bf16 16x16x32 MFMA path, 13-14: persistent ping-pong kernel; there split_k < 0 sets the workgroups per row panel), 21-23 a halo-conv tile */
+  int32_t tile;          /* 0 = auto; 1-16 force an implicit-GEMM tile (9-12: bf16 16x16x32 MFMA path, 13-14: persistent ping-pong kernel; there split_k < 0 sets the workgroups per row panel, 15-16: tiles 9 / 11 with the halo-staged A operand for stride-1 convolutions whose 256-row M-tile is whole lines of one image, W = 16 or 32), 21-23 the round-1 halo-conv kernel */
   float alpha;
   /* conv prologue (stride-1 halo path only): A := [silu](A*a_scale[b][ci] + a_shift[b][ci]) on
    * in-image pixels, applied ONCE per element in LDS before the zero padding -- the

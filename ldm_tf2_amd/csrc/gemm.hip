@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(GemmArgs p) {
 
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
-constexpr int kNumTiles = 15;
+constexpr int kNumTiles = 17;
 constexpr TileCfg kTiles[kNumTiles] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {256, 128},
                                        {128, 160}, {256, 160}, {128, 320},    // 6-8: N = 160*k layers
                                        // 9-12: bf16 v_mfma_f32_16x16x32 path, wave tiles 64 x 80 / 64 x 64;
@@ -158,13 +158,28 @@ constexpr TileCfg kTiles[kNumTiles] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}
                                        {256, 160}, {128, 160}, {256, 128}, {128, 128},
                                        // 13, 14: persistent ping-pong kernel (gemm3_kernel.h): a workgroup walks
                                        // several n-tiles of its 256-row panel, register epilogue
+                                       {256, 160}, {256, 128},
+                                       // 15, 16: tiles 9 / 11 with the HALO-STAGED A operand (gemm_kernel.h MODE 3):
+                                       // stride-1 convolutions whose M-tile is whole lines of one image
                                        {256, 160}, {256, 128}};
-constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2, 1, 1};   // workgroups per CU (LDS-limited)
-constexpr bool kBf16Only[kNumTiles] = {false, false, false, false, false, false, false, false, false, true, true, true, true, true, true};
-constexpr int kFirstPersistent = 13;
+constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2, 1, 1, 1, 1};   // workgroups per CU (LDS-limited)
+constexpr bool kBf16Only[kNumTiles] = {false, false, false, false, false, false, false, false, false, true, true, true, true, true, true,
+                                       true, true};
+constexpr bool is_persistent(int c) { return c == 13 || c == 14; }
+constexpr bool is_halo_ring(int c) { return c == 15 || c == 16; }
+// MODE 3 geometry: stride 1, pad 1, no upsample, the 256-row M-tile = 256 / W whole lines of ONE image
+bool halo_ring_ok(const ldm_gemm_params* p) {
+  return p->conv && p->stride == 1 && !p->upsample && !p->no_lead_pad && p->dtype == LDM_BF16 && p->batch == 1 &&
+         (p->W == 16 || p->W == 32) && 256 % p->W == 0 && p->H % (256 / p->W) == 0 && p->M % 256 == 0 &&
+         p->OH == p->H && p->OW == p->W;
+}
 
 template <typename T>
 void launch_mode(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  if (cfg == 15 || cfg == 16) {
+    if constexpr (sizeof(T) == 2) launch_cfg<T, 3>(cfg, a, grid, s);
+    return;
+  }
   if (!a.conv) launch_cfg<T, 0>(cfg, a, grid, s);
   else if (!a.upsample) launch_cfg<T, 1>(cfg, a, grid, s);
   else launch_cfg<T, 2>(cfg, a, grid, s);
@@ -178,8 +193,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // measured time one CU needs for one K-tile of that configuration with its resident
 // workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
-  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80, 1.03, 0.97};   // bf16, per round per K-tile (resident WGs co-running)
-  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4};   // launch + prologue + epilogue, in K-tiles
+  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80, 1.03, 0.97, 1.0, 0.94};   // bf16, per round per K-tile (resident WGs co-running)
+  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 9, 9};   // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
   static const bool no160 = getenv("LDM_GEMM_NO160") != nullptr;   // A/B switch for tools/
   const int bke = 128 / esize;
@@ -191,7 +206,7 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   for (int c = 1; c < kNumTiles; ++c) {
     if (p->tile > 0 && p->tile < kNumTiles && c != p->tile) continue;
     if (c == 5 && p->tile != 5) continue;   // experimental: only when forced
-    if (c >= kFirstPersistent && p->tile != c) continue;   // persistent kernel: only when forced (plan tables)
+    if (c >= 13 && p->tile != c) continue;   // persistent kernel, halo-staged conv tiles: only when forced (plan tables)
     if (c == 12 && p->tile != c) continue;   // 128x128 on the 16x16x32 path: no better than tile 2, only when forced
     if ((c == 1 || c == 7) && esize == 2 && p->tile != c) continue;   // bf16: their ping-ponged twins 11 / 9 are ~20 % faster
     if (c == 6 && esize == 2 && p->tile != 6) continue;   // bf16: tile 10 (same 128x160 tile, 64x80 wave tiles) is 10-14 % faster
@@ -203,7 +218,7 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
     const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
     for (int split : kSplits) {
       if (p->split_k > 0 && split != p->split_k) continue;
-      if (c >= kFirstPersistent && split > 1) continue;   // the persistent kernel does not split K
+      if (is_persistent(c) && split > 1) continue;   // the persistent kernel does not split K
       // split-K only rescues launches that cannot fill the machine once, and must fit
       // the caller's workspace
       if (split > 1 && (p->batch != 1 || ktiles / split < 4 || tiles >= 256.0 * kResident[c] ||
@@ -315,7 +330,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     cfg = kLnTile;
     split = 1;
   }
-  if (p->out2 && cfg < kFirstPersistent) {
+  if (p->out2 && !is_persistent(cfg)) {
     LDM_CHECK_ARG(!p->conv && p->batch == 1 && p->act != LDM_ACT_GEGLU && p->ldc_n == 1 && !p->ln_out && !p->residual,
                   "ldm_gemm: out2 needs plain rows, batch 1, a row-major first output, no GEGLU / ln_out");
     LDM_CHECK_ARG(p->n_split > 0 && p->n_split < p->N && p->n_split % kTiles[cfg].bn == 0,
@@ -326,7 +341,11 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   }
   if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5 || cfg == 11 || cfg == 12 || cfg == 14, "ldm_gemm: GEGLU needs a tile whose width is a multiple of 64 (1, 2, 5, 11, 12)");
   LDM_CHECK_ARG(!kBf16Only[cfg] || esize == 2, "ldm_gemm: tile %d is bf16 only", cfg);
-  if (cfg >= kFirstPersistent) {
+  if (is_halo_ring(cfg))
+    LDM_CHECK_ARG(halo_ring_ok(p) && p->N % kTiles[cfg].bn == 0 && !p->out2 && !p->ln_out,
+                  "ldm_gemm: tile %d (halo-staged conv) needs a bf16 stride-1 3x3 convolution with W = 16 or 32, "
+                  "H %% (256 / W) == 0, M %% 256 == 0 and N %% %d == 0", cfg, kTiles[cfg].bn);
+  if (is_persistent(cfg)) {
     // persistent ping-pong kernel: bf16 in/out, row-major 16-byte-aligned output, whole n-tiles
     const int bn = kTiles[cfg].bn;
     auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
@@ -403,6 +422,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   a.ktiles = cdiv(p->K, bke);
   a.split_k = split;
   a.ktiles_per_split = cdiv(a.ktiles, split);
+  if (is_halo_ring(cfg)) a.ktiles_per_split = cdiv(a.ktiles_per_split, 9) * 9;   // splits at whole channel chunks (9 taps)
   // drop empty trailing splits
   a.split_k = split = cdiv(a.ktiles, a.ktiles_per_split);
   if (split > 1) {

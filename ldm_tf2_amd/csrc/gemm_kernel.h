@@ -54,6 +54,18 @@ __device__ __forceinline__ void mma32(f32x16& acc, const u32x4& a, const u32x4& 
                                                0, 0, 0);
 }
 
+// element j of six values held in registers (selects on VALUES: a select between captured references
+// makes the compiler spill the whole closure to scratch and load through the selected pointer)
+__device__ __forceinline__ uint32_t pick6(int j, uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4, uint32_t a5) {
+  uint32_t v = a0;
+  v = j == 1 ? a1 : v;
+  v = j == 2 ? a2 : v;
+  v = j == 3 ? a3 : v;
+  v = j == 4 ? a4 : v;
+  v = j == 5 ? a5 : v;
+  return v;
+}
+
 // value before activation: acc(already * alpha) + bias[n] + addend[group(m)][n]
 __device__ __forceinline__ float epi_pre(const GemmArgs& p, int m, int n, float acc) {
   float v = acc * p.alpha;
@@ -82,6 +94,13 @@ __device__ __forceinline__ float apply_act(int act, float v) {
 }
 
 // MODE: 0 = plain rows, 1 = 3x3 conv (stride 1/2), 2 = 3x3 conv over the nearest-2x upsampled image
+//       3 = 3x3 conv, stride 1, HALO-STAGED A operand (bf16 ping-pong tiles only): the M-tile is BM / W
+//           whole lines of ONE image; per 64-channel chunk the (lines + 2) x (W + 2) input pixels are
+//           staged ONCE (<= 43 LDS-DMA pieces) and all nine taps read their A fragments from that patch
+//           at a row shift of kh (W + 2) + kw -- the XOR swizzle keys on the LDS row, and 16 consecutive
+//           rows at ANY alignment are conflict-free -- instead of one 32-piece A tile per tap (288 per
+//           chunk).  The patch of chunk c+1 lands while chunk c's nine taps are multiplied; only the
+//           weight tiles run through the 3-stage ring.
 // MF:   0 = v_mfma_f32_32x32x16 (wave tile = TM x TN blocks of 32x32)
 //       1 = v_mfma_f32_16x16x32_bf16 (bf16 only; wave tile = blocks of 16x16, e.g. 64 x 80: the
 //           N = 160*k layers get a 2.2x larger wave tile per LDS byte read than 32 x 160)
@@ -111,15 +130,22 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   constexpr int ES = (int)sizeof(T);
   constexpr int EPC = 16 / ES;
   constexpr int BKE = 8 * EPC;
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr bool RING = MODE == 3;
+  static_assert(!RING || (MF == 1 && ST == 1 && sizeof(T) == 2 && BM == 256), "halo-staged conv: bf16 ping-pong tiles");
+  constexpr int PROWS = 344;                       // >= (BM/32 + 2) * 34 = 340 and (BM/16 + 2) * 18 = 324 patch rows
+  constexpr int PATCH = PROWS * 128;
+  constexpr int LAP = (PROWS / 8 + NW - 1) / NW;   // patch pieces (8 rows) per wave
+  constexpr int STAGE = RING ? BN * 128 : (BM + BN) * 128;
   // A third stage (prefetch distance 2) only where it is free: tiles whose two stages already
   // leave room for just one workgroup per CU (160 KB LDS) and whose three stages still fit.
   constexpr int kLds = 160 * 1024;
-  constexpr int NSTAGE = (4 * STAGE > kLds && 3 * STAGE <= kLds && WM * WN == 8) ? 3 : 2;
+  constexpr int NSTAGE = RING ? 3 : (4 * STAGE > kLds && 3 * STAGE <= kLds && WM * WN == 8) ? 3 : 2;
+  constexpr int RINGB = RING ? 2 * PATCH : 0;      // bytes of the two halo patches in front of the weight ring
   // the 160/320-column tiles stage their f32 epilogue tile in two row passes (LDS budget)
   constexpr int ESPLIT = (BN % 160 == 0 && WM >= 2) ? 2 : 1;
   constexpr int EROWS = BM / ESPLIT;
-  constexpr int SMEM = NSTAGE * STAGE > EROWS * BN * 4 ? NSTAGE * STAGE : EROWS * BN * 4;
+  constexpr int SMEM = RINGB + NSTAGE * STAGE > EROWS * BN * 4 ? RINGB + NSTAGE * STAGE : EROWS * BN * 4;
+  static_assert(SMEM <= kLds, "LDS");
   static_assert(LA >= 1 && LB >= 1 && TM >= 1 && TN >= 1 && BM % (8 * NW) == 0 && BN % 8 == 0, "tile");
   static_assert(WTM % MB == 0 && WTN % MB == 0, "wave tile must be whole MFMA blocks");
   static_assert(!MF || (ES == 2 && WTM % 16 == 0 && (WTN / 2) % 8 == 0), "16x16x32 path: bf16, swizzle-aligned wave tiles");
@@ -263,6 +289,64 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     }
   };
 
+  // ---- MODE 3: halo patch geometry ----------------------------------------------------------
+  // patch row = line * (W + 2) + px', line 0 = image line l0 - 1, px' 0 = pixel -1.  Piece slot j of
+  // this wave covers patch rows (j NW + wave) 8 .. + 7; a lane fetches the chunk its LDS row's swizzle
+  // asks for, or nothing (range check -> zeros) where the pixel lies outside the image.
+  static_assert(!RING || LAP == 6, "patch piece slots");
+  [[maybe_unused]] uint32_t ao0 = kOOB, ao1 = kOOB, ao2 = kOOB, ao3 = kOOB, ao4 = kOOB, ao5 = kOOB;   // (scalars: an array
+  [[maybe_unused]] int prow0[TM];                    // indexed by the runtime tap would be demoted to LDS)
+  [[maybe_unused]] int pw = 0, prows = 0;
+  if constexpr (RING) {
+    const int lines = BM / p.W;                     // whole image lines per M-tile (host-checked)
+    pw = p.W + 2;
+    prows = (lines + 2) * pw;
+    const int tpi = p.H / lines;                    // M-tiles per image
+    const int img = tile_m / tpi, l0 = (tile_m - img * tpi) * lines;
+    auto piece_off = [&](int j) __attribute__((always_inline)) -> uint32_t {
+      const int row = (j * NW + wave) * 8 + (lane >> 3);
+      const int ck = (lane & 7) ^ ((row >> 1) & 7);
+      const int line = row / pw, px = row - line * pw - 1;
+      const int iy = l0 - 1 + line;
+      if (row < prows && (unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W && m0 < p.M)
+        return (uint32_t)((((int64_t)img * p.H + iy) * p.W + px) * p.lda * ES) + ck * 16;
+      return kOOB;
+    };
+    ao0 = piece_off(0); ao1 = piece_off(1); ao2 = piece_off(2);
+    ao3 = piece_off(3); ao4 = piece_off(4); ao5 = piece_off(5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wm * WTM + i * MB + (lane & 15);          // output row of this lane in block i
+      const int line = r / p.W;
+      prow0[i] = line * pw + (r - line * p.W);                  // tap (0, 0): + kh pw + kw per tap
+    }
+  }
+  // one patch piece (slot j = 0..5, a runtime value in the main loop)
+  [[maybe_unused]] auto issue_patch_piece = [&](int lc, int chunk, int j) __attribute__((always_inline)) -> int {
+    if constexpr (RING) {
+      if ((j * NW + wave) * 8 >= prows) return 0;               // wave-uniform
+      const uint32_t off = pick6(j, ao0, ao1, ao2, ao3, ao4, ao5);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr)(smem + (lc & 1) * PATCH + (j * NW + wave) * 1024), 16,
+                                               off + (uint32_t)chunk * 128u, 0, 0, 0);
+      return 1;
+    }
+    return 0;
+  };
+  // weight tile of step (chunk, tap) into ring stage `stage`
+  [[maybe_unused]] auto issue_w = [&](int chunk, int tap, int stage) __attribute__((always_inline)) {
+    if constexpr (RING) {
+      char* dB = smem + RINGB + stage * STAGE + wave * 1024;
+      const uint32_t kb = (uint32_t)(tap * p.Cin * ES + chunk * 128);
+#pragma unroll
+      for (int i = 0; i < LBF; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dB + i * NW * 1024), 16, (uint32_t)b_base[i] + kb, 0, 0, 0);
+      if constexpr (LB != LBF) {
+        if (b_last)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr)(dB + LBF * NW * 1024), 16, (uint32_t)b_base[LBF] + kb, 0, 0, 0);
+      }
+    }
+  };
+
   typedef float AccV __attribute__((ext_vector_type(NR)));
   AccV acc[TM][TN];
 #pragma unroll
@@ -285,7 +369,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   for (int kg = 0; kg < KS; ++kg) {
     const int coff = ((MF ? (kg * 4 + lh) : (kg * 2 + lh)) ^ sw) << 4;
     offA[kg] = (wm * WTM + lr) * 128 + coff;
-    offB[kg] = BM * 128 + (wn * WTN + lr) * 128 + coff;
+    offB[kg] = (RING ? 0 : BM * 128) + (wn * WTN + lr) * 128 + coff;
   }
 
   // 2-stage ring, prefetch distance 1: at the top of K-tile t every outstanding LDS-DMA
@@ -294,8 +378,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // 3-stage ring (NSTAGE == 3), prefetch distance 2: tiles t and t+1 are outstanding at the
   // top of K-tile t, so the wait is the counted vmcnt(this wave's loads per tile) -- tile t+1's
   // LDS-DMAs may still be in flight -- and tile t+2 goes to the stage tile t-1 was read from.
-  if (nk > 0) issue_tile(kt_begin, 0);
-  if (NSTAGE == 3 && nk > 1) issue_tile(kt_begin + 1, 1);
+  if constexpr (!RING) {
+    if (nk > 0) issue_tile(kt_begin, 0);
+    if (NSTAGE == 3 && nk > 1) issue_tile(kt_begin + 1, 1);
+  }
   u32x4 fa[KS][TM], fb[KS][TN];
   auto wait_tile = [&](int t) {                      // this wave's LDS-DMAs of tile t have landed
     if (NSTAGE == 3 && t + 1 < nk) {
@@ -336,7 +422,96 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   };
   int st = 0;
   const bool late = ST && wave >= NW / 2;            // wave-uniform (wave is a readfirstlane)
-  if (!late) {
+  if constexpr (RING) {
+    // Step s = (local chunk lc, tap): weight tile s in ring stage s % 3, A fragments from patch lc & 1.
+    // After the barrier of step s a wave issues [patch piece `tap` of chunk lc + 1][weight tile s + 2];
+    // at the top of step s the operations younger than weight tile s are therefore the previous
+    // step's patch piece (if it issued one) and weight tile s + 1: the counted wait leaves exactly
+    // those in flight.  The patch of chunk lc + 1 is complete long before its first use (its pieces go
+    // out at taps 0-5 of chunk lc and are older than weight tile 9 (lc + 1)).
+    const int nchunks = nk / 9, c_begin = kt_begin / 9;
+#pragma unroll
+    for (int j = 0; j < LAP; ++j) issue_patch_piece(0, c_begin, j);
+    if (nk > 0) issue_w(c_begin, 0, 0);
+    if (nk > 1) issue_w(c_begin, 1, 1);
+    int lc = 0, tap = 0, prev_a = 0;
+    auto wait_step = [&](int s) __attribute__((always_inline)) {
+      if (s + 1 < nk) {
+        const int extra = prev_a + (b_last ? 1 : 0);             // wave-uniform
+        if (extra == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB + 1) : "memory");
+        else if (extra == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB - 1) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    };
+    auto stage_next = [&](int s) __attribute__((always_inline)) {
+      prev_a = 0;
+      if (tap < LAP && lc + 1 < nchunks) prev_a = issue_patch_piece(lc + 1, c_begin + lc + 1, tap);
+      if (s + 2 < nk) {
+        int t2 = tap + 2, c2 = lc;
+        if (t2 >= 9) { t2 -= 9; ++c2; }
+        int s2 = st + 2;
+        s2 = s2 >= 3 ? s2 - 3 : s2;
+        issue_w(c_begin + c2, t2, s2);
+      }
+    };
+    // A fragment addresses of the CURRENT step, computed one step ahead (while the previous step's
+    // fragment reads are in flight): the tap's row shift moves the swizzle key, so they are not a
+    // constant plus an offset
+    int adr[KS][TM];
+    auto calc_addr = [&]() __attribute__((always_inline)) {
+      const int kh = tap / 3, kw = tap - 3 * kh;
+      const int shift = kh * pw + kw;
+      const int pbase = (lc & 1) * PATCH;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = prow0[i] + shift;
+        const int sw = (row >> 1) & 7;
+#pragma unroll
+        for (int kg = 0; kg < KS; ++kg) adr[kg][i] = pbase + row * 128 + (((kg * 4 + lh) ^ sw) << 4);
+      }
+    };
+    calc_addr();
+    auto read_ring = [&]() __attribute__((always_inline)) {
+      const char* cB = smem + RINGB + st * STAGE;
+#pragma unroll
+      for (int kg = 0; kg < KS; ++kg) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[kg][i] = *(const u32x4*)(smem + adr[kg][i]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[kg][j] = *(const u32x4*)(cB + offB[kg] + j * MB * 128);
+      }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {
+      st = st + 1 == 3 ? 0 : st + 1;
+      if (++tap == 9) { tap = 0; ++lc; }
+    };
+    if (!late) {
+      for (int s = 0; s < nk; ++s) {
+        wait_step(s);
+        __builtin_amdgcn_s_barrier();
+        stage_next(s);
+        read_ring();
+        advance();
+        calc_addr();
+        multiply();
+      }
+    } else {
+      for (int s = 0; s < nk; ++s) {
+        wait_step(s);
+        __builtin_amdgcn_s_barrier();
+        if (s > 0) multiply();
+        stage_next(s);
+        read_ring();
+        advance();
+        calc_addr();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (nk > 0) multiply();
+    }
+  } else if (!late) {
     for (int t = 0; t < nk; ++t) {
       wait_tile(t);
       __builtin_amdgcn_s_barrier();

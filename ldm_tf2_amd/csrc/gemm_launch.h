@@ -7,6 +7,12 @@ namespace ldm_gemm_detail {
 
 template <typename T, int MODE>
 void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
+  if constexpr (MODE == 3) {   // halo-staged stride-1 convolution: tiles 15 (256x160) / 16 (256x128), bf16 only
+    if constexpr (sizeof(T) == 2) {
+      if (cfg == 15) hipLaunchKernelGGL((gemm_kernel<T, 256, 160, 4, 2, 3, 1, 1>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2, 3, 1, 1>), grid, dim3(512), 0, s, a);
+    }
+  } else
   switch (cfg) {
     case 1: hipLaunchKernelGGL((gemm_kernel<T, 256, 128, 4, 2, MODE>), grid, dim3(512), 0, s, a); break;
     case 2: hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;

@@ -126,9 +126,21 @@ _PLAN_RECORD = None
 _TILE_DIMS = {1: (256, 128, 1), 2: (128, 128, 2), 3: (128, 64, 3), 4: (64, 64, 5), 6: (128, 160, 2),
               7: (256, 160, 1), 8: (128, 320, 1),       # BM, BN, resident workgroups per CU
               9: (256, 160, 1), 10: (128, 160, 2), 11: (256, 128, 1), 12: (128, 128, 2),   # bf16 16x16x32 MFMA path
-              13: (256, 160, 1), 14: (256, 128, 1)}     # persistent ping-pong kernel (no split-K, N % BN == 0)
-_BF16_TILES = (9, 10, 11, 12, 13, 14)
+              13: (256, 160, 1), 14: (256, 128, 1),     # persistent ping-pong kernel (no split-K, N % BN == 0)
+              15: (256, 160, 1), 16: (256, 128, 1)}     # tiles 9 / 11 with the halo-staged A operand (stride-1 convs)
+_BF16_TILES = (9, 10, 11, 12, 13, 14, 15, 16)
 _PERSISTENT_TILES = (13, 14)
+_HALO_RING_TILES = (15, 16)
+
+
+def _halo_ring_key(key, M, N, bn):
+  """True if the problem `key` names can run on a halo-staged conv tile (gemm.hip halo_ring_ok)."""
+  import re
+  m = re.search(r"conv1 H(\d+) W(\d+) s1 u0 nlp0", key or "")
+  if not m:
+    return False
+  H, W = int(m.group(1)), int(m.group(2))
+  return W in (16, 32) and H % (256 // W) == 0 and M % 256 == 0 and N % bn == 0
 
 
 def plan_key(p) -> str:
@@ -229,11 +241,14 @@ def record_plan_keys(sink):
   _PLAN_RECORD = sink
 
 
-def plan_candidates(M, N, K, batch, act, dtype):
-  """(tile, split_k) pairs worth timing for one problem."""
+def plan_candidates(M, N, K, batch, act, dtype, key=None):
+  """(tile, split_k) pairs worth timing for one problem (`key`: its plan key, which carries the conv
+  geometry the halo-staged tiles depend on)."""
   ktiles = K // (64 if dtype == BF16 else 32)
   out = []
   for tile, (bm, bn, res) in _TILE_DIMS.items():
+    if tile in _HALO_RING_TILES and not (dtype == BF16 and batch == 1 and _halo_ring_key(key, M, N, bn)):
+      continue
     if act == ACT_GEGLU and tile not in (1, 2, 11, 12, 14):
       continue
     if tile in _BF16_TILES and dtype != BF16:

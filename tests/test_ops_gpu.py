@@ -499,6 +499,55 @@ def test_conv3x3_small_in_paths(dev, dtype, B, H, W, Cin, Cout):
   assert (wide[..., :64].float() == 7.0).all()
 
 
+# ---- halo-staged stride-1 convolution (tiles 15 = 256x160, 16 = 256x128; gemm_kernel.h MODE 3) -------
+@pytest.mark.parametrize("cfg", [
+    dict(B=2, H=32, W=32, Cin=128, Cout=320),      # 4 M-tiles per image (8 lines each), 2 channel chunks
+    dict(B=3, H=16, W=16, Cin=192, Cout=640),      # one image per M-tile, 3 chunks (odd: both patch buffers end the loop)
+    dict(B=1, H=32, W=32, Cin=64, Cout=128),       # ONE chunk: the prologue patch only
+    dict(B=2, H=16, W=16, Cin=320, Cout=160),      # 5 chunks
+])
+def test_conv3x3_halo_ring(dev, cfg):
+  """Every tap reads its A fragments from the staged (lines + 2) x (W + 2) patch at a row shift: image
+  borders (zero padding comes from the staging range check), tile borders inside an image (halo lines
+  of the neighbouring tile), bias + per-sample addend + residual epilogue, split-K at chunk borders."""
+  o = ops()
+  dtype = torch.bfloat16
+  B, H, W, Cin, Cout = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"]
+  x = rnd((B, H, W, Cin), dtype, 1)
+  k = rnd((3, 3, Cin, Cout), dtype, 2, (9 * Cin) ** -0.5)
+  bias = rnd((Cout,), torch.float32, 3)
+  addend = rnd((B, Cout), torch.float32, 4)
+  res = rnd((B, H, W, Cout), dtype, 6)
+  ref = O.conv2d(x.float(), k.float(), bias) + addend[:, None, None, :] + res.float()
+  wt = k.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous().to(dev)
+  ran = 0
+  for tile in (15, 16):
+    if Cout % (160 if tile == 15 else 128):
+      continue
+    for split in (1, 2, 3):
+      if split > Cin // 64:
+        continue
+      out = torch.zeros(B, H, W, Cout, dtype=dtype, device=dev)
+      o.conv3x3(x.to(dev), wt, out, bias=bias.to(dev), addend=addend.to(dev), residual=res.to(dev), tile=tile,
+                split_k=split)
+      close(out, ref, dtype)
+      ran += 1
+  assert ran
+  # a channel slice of a wider buffer as input (pixel stride > Cin), as the U-Net's concat buffers are
+  wide = rnd((B, H, W, Cin + 64), dtype, 7).to(dev)
+  xs = wide[..., 64:]
+  ref2 = O.conv2d(xs.float().cpu(), k.float(), bias)
+  tile = 15 if Cout % 160 == 0 else 16
+  out = torch.zeros(B, H, W, Cout, dtype=dtype, device=dev)
+  o.conv3x3(xs, wt, out, bias=bias.to(dev), tile=tile)
+  close(out, ref2, dtype)
+  from ldm_tf2_amd._lib import LdmHipError
+  with pytest.raises(LdmHipError):                                       # stride 2: not a halo-ring problem
+    o.conv3x3(x.to(dev), wt, torch.zeros(B, H // 2, W // 2, Cout, dtype=dtype, device=dev), stride=2, tile=tile)
+  with pytest.raises(LdmHipError):                                       # f32: bf16 tiles only
+    o.conv3x3(x.float().to(dev), wt.float(), torch.zeros(B, H, W, Cout, device=dev), tile=tile)
+
+
 # ---- persistent ping-pong kernel (tiles 13 = 256x160, 14 = 256x128; gemm3_kernel.h) ---------------
 @pytest.mark.parametrize("tile,N", [(13, 320), (13, 1280), (14, 384), (14, 1152)])
 @pytest.mark.parametrize("M,K,nsplit", [(300, 320, 0), (1000, 384, 1), (777, 64, 2), (4096, 640, 0)])

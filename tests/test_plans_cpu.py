@@ -96,8 +96,8 @@ def test_packaged_plans_are_legal():
     plans = json.load(open(path))["plans"]
     for key, (tile, split) in plans.items():
       f = dict((k.rstrip("0123456789"), int(k[len(k.rstrip("0123456789")):])) for k in key.split())
-      assert tile in (1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14) and split >= 1, (path, key)
-      assert (tile, split) in ops.plan_candidates(f["M"], f["N"], f["K"], f["b"], f["act"], f["dt"]), (path, key)
+      assert tile in (1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16) and split >= 1, (path, key)
+      assert (tile, split) in ops.plan_candidates(f["M"], f["N"], f["K"], f["b"], f["act"], f["dt"], key=key), (path, key)
       # the library accepts the forced pair for planning purposes
       p = _params(f["M"], f["N"], f["K"], conv=f["conv"], act=f["act"], dtype=f["dt"])
       p.tile, p.split_k = tile, split
@@ -105,3 +105,19 @@ def test_packaged_plans_are_legal():
       t, s = C.c_int(), C.c_int()
       assert lib.ldm_gemm_plan(C.byref(p), C.byref(t), C.byref(s)) == 0
       assert t.value == tile
+
+
+def test_halo_ring_candidates_follow_the_conv_geometry():
+  """Tiles 15 / 16 are only offered where the library runs them: stride-1 convs with W = 16 / 32 whose
+  256-row M-tile is whole lines of one image (the plan key carries the geometry)."""
+  k32 = "M32768 N320 K2880 b1 conv1 H32 W32 s1 u0 nlp0 act0 dt1 odt1"
+  k8 = "M2048 N1280 K11520 b1 conv1 H8 W8 s1 u0 nlp0 act0 dt1 odt1"
+  ks2 = "M8192 N320 K2880 b1 conv1 H32 W32 s2 u0 nlp0 act0 dt1 odt1"
+  kup = "M32768 N640 K5760 b1 conv1 H16 W16 s1 u1 nlp0 act0 dt1 odt1"
+  tiles = lambda key, M, N, K, dt=ops.BF16: {t for t, _ in ops.plan_candidates(M, N, K, 1, 0, dt, key=key)}
+  assert 15 in tiles(k32, 32768, 320, 2880) and 16 not in tiles(k32, 32768, 320, 2880)      # 320 = 2 x 160
+  assert not {15, 16} & tiles(k8, 2048, 1280, 11520)
+  assert not {15, 16} & tiles(ks2, 8192, 320, 2880)
+  assert not {15, 16} & tiles(kup, 32768, 640, 5760)
+  assert not {15, 16} & tiles(k32.replace("dt1 odt1", "dt0 odt0"), 32768, 320, 2880, ops.F32)
+  assert not {15, 16} & tiles(None, 32768, 320, 2880)

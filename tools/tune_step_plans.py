@@ -101,7 +101,7 @@ def main():
     start = ops.gemm_plans().get(key)
     best_c, best_ms = start, cur
     only = {int(t) for t in args.tiles.split(",")} if args.tiles else None
-    for cand in ops.plan_candidates(M, N, K, batch, act, dtype):
+    for cand in ops.plan_candidates(M, N, K, batch, act, dtype, key=key):
       if only is not None and cand[0] not in only:
         continue
       if key.endswith(" t1") and cand[0] not in (13, 14):     # whole-product-transposed launches: persistent kernel only
