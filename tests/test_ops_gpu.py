@@ -505,6 +505,8 @@ def test_conv3x3_small_in_paths(dev, dtype, B, H, W, Cin, Cout):
     dict(B=3, H=16, W=16, Cin=192, Cout=640),      # one image per M-tile, 3 chunks (odd: both patch buffers end the loop)
     dict(B=1, H=32, W=32, Cin=64, Cout=128),       # ONE chunk: the prologue patch only
     dict(B=2, H=16, W=16, Cin=320, Cout=160),      # 5 chunks
+    dict(B=2, H=32, W=16, Cin=64, Cout=128),       # non-square: two 16-line tiles per image
+    dict(B=4, H=8, W=32, Cin=128, Cout=160),       # an 8-line image = exactly one tile
 ])
 def test_conv3x3_halo_ring(dev, cfg):
   """Every tap reads its A fragments from the staged (lines + 2) x (W + 2) patch at a row shift: image
