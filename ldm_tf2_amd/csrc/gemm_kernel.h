@@ -97,8 +97,8 @@ __device__ __forceinline__ float apply_act(int act, float v) {
 //       3 = 3x3 conv, stride 1, HALO-STAGED A operand (bf16 ping-pong tiles only): the M-tile is BM / W
 //           whole lines of ONE image; per 64-channel chunk the (lines + 2) x (W + 2) input pixels are
 //           staged ONCE (<= 43 LDS-DMA pieces) and all nine taps read their A fragments from that patch
-//           at a row shift of kh (W + 2) + kw -- the XOR swizzle keys on the LDS row, and 16 consecutive
-//           rows at ANY alignment are conflict-free -- instead of one 32-piece A tile per tap (288 per
+//           at a row shift of kh (W + 2) + kw (the patch has its own swizzle key, row & 7, which keeps the
+//           16x16x32 fragment reads conflict-free at every shift) instead of one 32-piece A tile per tap (288 per
 //           chunk).  The patch of chunk c+1 lands while chunk c's nine taps are multiplied; only the
 //           weight tiles run through the 3-stage ring.
 // MF:   0 = v_mfma_f32_32x32x16 (wave tile = TM x TN blocks of 32x32)
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
     const int img = tile_m / tpi, l0 = (tile_m - img * tpi) * lines;
     auto piece_off = [&](int j) __attribute__((always_inline)) -> uint32_t {
       const int row = (j * NW + wave) * 8 + (lane >> 3);
-      const int ck = (lane & 7) ^ ((row >> 1) & 7);
+      const int ck = (lane & 7) ^ (row & 7);          // patch swizzle: see calc_addr
       const int line = row / pw, px = row - line * pw - 1;
       const int iy = l0 - 1 + line;
       if (row < prows && (unsigned)iy < (unsigned)p.H && (unsigned)px < (unsigned)p.W && m0 < p.M)
@@ -466,8 +466,13 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
       const int pbase = (lc & 1) * PATCH;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
+        // The patch is swizzled by chunk ^ (row & 7), not by the (row >> 1) key of the tiles: a tap moves
+        // the fragment rows by an arbitrary shift, and for the 16x16x32 fragment read (ds_read_b128 is
+        // served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) only the row & 7 key is
+        // conflict-free at EVERY shift (the tiles' key: 2-way conflicts at odd shifts, 4-way at shifts
+        // = 2 mod 4 -- measured 17x the bank-conflict cycles of tile 9 before this was changed).
         const int row = prow0[i] + shift;
-        const int sw = (row >> 1) & 7;
+        const int sw = row & 7;
 #pragma unroll
         for (int kg = 0; kg < KS; ++kg) adr[kg][i] = pbase + row * 128 + (((kg * 4 + lh) ^ sw) << 4);
       }
