@@ -29,6 +29,9 @@
 //     scattered stores).
 //   * workgroup ids are remapped so that the tiles sharing an A row-panel run
 //     on one XCD (its L2 then serves the panel's re-reads).
+//   * stride-1 convolutions at the 32x32 / 16x16 levels can run with a HALO-STAGED A operand (tiles
+//     15 / 16, gemm_kernel.h MODE 3): the (lines + 2) x (W + 2) input pixels of a 64-channel chunk are
+//     staged once and serve all nine taps; only the weight tiles go through the stage ring.
 //   * small-M layers (4x4 / 8x8 feature maps) stream their weights with split-K
 //     over all CUs; partial sums go to an f32 workspace and a second kernel
 //     reduces + applies the epilogue.
