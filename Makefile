@@ -19,7 +19,23 @@ $(OUT): $(OBJS)
 	@mkdir -p $(dir $(OUT))
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 
-clean:
-	rm -rf build $(OUT)
+# Tools build: the same sources with -DLDM_TOOLS_BUILD (timing ablations of the persistent kernel,
+# A/B environment switches of the tile cost model).  Never loaded by the product path: tools/ load it
+# explicitly (tools/toolslib.py).  The product library reads no result-changing environment variable.
+TOUT  := ldm_tf2_amd/lib/libldm_hip_tools.so
+TOBJS := $(patsubst $(CSRC)/%.hip,build_tools/%.o,$(SRCS))
 
-.PHONY: all clean
+build_tools/%.o: $(CSRC)/%.hip $(HDRS)
+	@mkdir -p build_tools
+	$(HIPCC) $(CXXFLAGS) -DLDM_TOOLS_BUILD -c $< -o $@
+
+$(TOUT): $(TOBJS)
+	@mkdir -p $(dir $(TOUT))
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(TOBJS)
+
+tools: $(TOUT)
+
+clean:
+	rm -rf build build_tools $(OUT) $(TOUT)
+
+.PHONY: all clean tools

@@ -210,7 +210,9 @@ int ldm_softmax_rows(const void* x, int64_t ldx, int in_dtype, void* out, int64_
  * Fused multi-head attention, logits never materialised:
  *   out[b][q][h][:] = softmax_c( scale * q[b][q][h][:] . k[b][c][h][:] ) @ v[b][c][h][:]
  * q: [batch][Tq] rows of heads*Sp elements (row stride ldq), k likewise [batch][Tk];
- * vt: V transposed per head: [batch][heads][Sp][ldvt] with ldvt >= Tk keys contiguous;
+ * vt: V transposed per head: [batch][heads][Sp][ldvt] with ldvt >= Tk keys contiguous and ldvt a
+ *     multiple of 16 bytes; the padding columns [Tk, ldvt) are read in whole 16-byte chunks but
+ *     masked to zero in the kernel: they need not be initialised (NaN / Inf there are harmless);
  * out: [batch][Tq] rows of heads*Sp (row stride ldo).  Sp = head size padded to a
  * multiple of 32 with zeros (the padding lives in the re-laid-out projection weights).
  * Replaces unet.py:280-287 and transformer.py:107-116 (scale applied AFTER q.k^T).

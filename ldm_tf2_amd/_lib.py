@@ -9,10 +9,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libldm_hip.so")
+# LDM_HIP_LIB=<file>: load another build of the same ABI (tools/ use it for the -DLDM_TOOLS_BUILD
+# library with its timing ablations, `make tools`); the product library itself reads no
+# result-changing environment variable
+LIB_PATH = os.environ.get("LDM_HIP_LIB") or os.path.join(_HERE, "lib", "libldm_hip.so")
 
 F32, BF16 = 0, 1
 ACT_NONE, ACT_GELU, ACT_GEGLU, ACT_SILU = 0, 1, 2, 3
+OK, ERR_ARG, ERR_LAUNCH, ERR_WORKSPACE = 0, -1, -2, -3     # include/ldm_hip.h status codes
 
 c_i64, c_i32, c_f32, c_vp, c_sz = C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_size_t
 

@@ -15,6 +15,7 @@
 // KT keys are staged global -> registers -> LDS with the next tile's loads in
 // flight during the current tile's MFMAs.  Logits are never written to memory.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -34,6 +35,23 @@ __device__ __forceinline__ void mma32a(f32x16& acc, const u32x4& a, const u32x4&
   for (int j = 0; j < 4; ++j)
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a[j]), __uint_as_float(b[j]), acc,
                                                0, 0, 0);
+}
+
+
+// Keeps the first `nvalid` elements of a 16-byte chunk of V^T and zeroes the rest: the columns
+// [Tk, ldvt) of vt are padding the kernel must not depend on (P is 0 there, but 0 x NaN = NaN in the
+// MFMA, so a caller's uninitialised padding would poison the output).  Only the chunk that crosses Tk
+// pays for it.
+template <typename T>
+__device__ __forceinline__ u32x4 keep_first(u32x4 v, int nvalid) {
+  constexpr int EPW = 4 / (int)sizeof(T);          // elements per 32-bit word
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int left = nvalid - w * EPW;              // valid elements from this word on
+    if (left <= 0) v[w] = 0u;
+    else if (EPW == 2 && left == 1) v[w] &= 0xffffu;
+  }
+  return v;
 }
 
 template <typename T> struct AttnTraits;
@@ -130,8 +148,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
       const int id = tid + i * 256;
       const int dim = id / VCH, kc = id - dim * VCH;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (id < SP * VCH && kt0 + kc * EPC < p.ldvt)
+      const int left = p.Tk - (kt0 + kc * EPC);        // keys of this chunk that exist
+      if (id < SP * VCH && left > 0) {
         v = *(const u32x4*)(Vt + (int64_t)dim * p.ldvt + kt0 + kc * EPC);
+        if (left < EPC) v = keep_first<T>(v, left);
+      }
       rv[i] = v;
     }
   };
@@ -327,7 +348,11 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(AttnArgs p) {
       const int id = tid + i * 256;
       const int dim = id / VCH, kc = id - dim * VCH;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (kt0 + kc * EPC < p.ldvt) v = *(const u32x4*)(Vt + (int64_t)dim * p.ldvt + kt0 + kc * EPC);
+      const int left = p.Tk - (kt0 + kc * EPC);        // keys of this chunk that exist
+      if (left > 0) {
+        v = *(const u32x4*)(Vt + (int64_t)dim * p.ldvt + kt0 + kc * EPC);
+        if (left < EPC) v = keep_first<T>(v, left);
+      }
       *(u32x4*)(sV + dim * VRS + kc * 16) = v;
     }
     __syncthreads();
@@ -434,11 +459,16 @@ template <typename T>
 int launch_attn_wide(const AttnArgs& a, int batch, hipStream_t s) {
   constexpr int ES = (int)sizeof(T);
   const int lds = 32 * (512 * ES + 16) + 512 * (32 * ES + 16) + 4 * 64 * 16 * 4;
-  static bool attr_set = false;      // per element type (template instance)
-  if (!attr_set) {
+  // the attribute belongs to the (kernel, DEVICE) pair: remember it per device, atomically (two host
+  // threads may launch at once; setting it twice is harmless)
+  static std::atomic<uint64_t> attr_set{0};      // bit d = done on device d; per element type (template instance)
+  int devid = 0;
+  if (hipGetDevice(&devid) != hipSuccess) return -1;
+  const uint64_t bit = devid < 64 ? (1ull << devid) : 0;
+  if (!(attr_set.load(std::memory_order_acquire) & bit) || !bit) {
     if (hipFuncSetAttribute((const void*)attn_wide_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return -1;
-    attr_set = true;
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
   dim3 grid((a.Tq + 31) / 32, a.heads, batch);
   hipLaunchKernelGGL((attn_wide_kernel<T>), grid, dim3(256), lds, s, a);

@@ -199,7 +199,12 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80, 1.03, 0.97, 1.0, 0.94};   // bf16, per round per K-tile (resident WGs co-running)
   static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 9, 9};   // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
-  static const bool no160 = getenv("LDM_GEMM_NO160") != nullptr;   // A/B switch for tools/
+#ifdef LDM_TOOLS_BUILD
+  static const bool no160 = getenv("LDM_GEMM_NO160") != nullptr;   // A/B switch, tools build only
+  static const bool no_t2pref = getenv("LDM_GEMM_NO_T2PREF") != nullptr;
+#else
+  constexpr bool no160 = false, no_t2pref = false;
+#endif
   const int bke = 128 / esize;
   const int ktiles = cdiv(p->K, bke);
   const bool geglu = p->act == LDM_ACT_GEGLU;
@@ -233,7 +238,6 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
       // calibration (tools/splitk_sweep.py): when the 256x128 tiling cannot fill the chip once
       // (small-M convolutions: 4x4 / 8x8 / 16x16 maps), two co-resident 128x128 workgroups per
       // CU measure 5-14 % faster than one 256x128 at the same split
-      static const bool no_t2pref = getenv("LDM_GEMM_NO_T2PREF") != nullptr;   // A/B switch
       if (!no_t2pref && c == 2 && (double)cdiv(p->M, 256) * cdiv(p->N, 128) * p->batch < 256.0) us *= 0.9;
       if (split > 1) us += 3.0 + (double)p->M * p->N * 4.0 * (split + 1) / 3.0e6;   // bytes / (3 TB/s) in us
       if (us < best) { best = us; best_cfg = c; best_split = split; }
@@ -317,8 +321,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   // kernel of conv_halo.hip.  Without a prologue the implicit-GEMM kernel measures equal or
   // faster, so it stays the default.
   // (forced halo tiles are addressed as tile 21..23)
-  static const bool no_halo = getenv("LDM_NO_HALO") != nullptr;   // A/B switch, read once
-  if (p->conv && p->stride == 1 && ((p->tile == 0 && p->a_scale) || p->tile > 20) && p->split_k <= 1 && !no_halo) {
+  if (p->conv && p->stride == 1 && ((p->tile == 0 && p->a_scale) || p->tile > 20) && p->split_k <= 1) {
     const int r = ldm_conv_halo_try(p, p->tile > 20 ? p->tile - 20 : 0, stream);
     if (r == 1) return LDM_OK;
     if (r < 0) return r;
@@ -380,7 +383,9 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     g.stride = p->stride; g.upsample = p->upsample; g.pad = p->no_lead_pad ? 0 : 1;
     g.act = p->act;
     LDM_CHECK_ARG(p->alpha == 1.0f, "ldm_gemm: tile %d (persistent) needs alpha == 1", cfg);
-    { static const int dbg = getenv("LDM_G3_DEBUG") ? atoi(getenv("LDM_G3_DEBUG")) : 0; g.dbg = dbg; }
+#ifdef LDM_TOOLS_BUILD
+    { static const int dbg = getenv("LDM_G3_DEBUG") ? atoi(getenv("LDM_G3_DEBUG")) : 0; g.dbg = dbg; }   // timing ablations
+#endif
     g.ktiles = p->K / 64;
     g.panels = cdiv(p->M, 256);
     g.ntiles = p->N / bn;

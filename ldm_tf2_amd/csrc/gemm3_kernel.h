@@ -44,15 +44,34 @@ struct Gemm3Args {
   char* out_t;        // transposed output (EPI bit 5): out_t[(m / rows_t) * stride_t + n * ld_t + m % rows_t]
   int64_t ld_t, stride_t;
   int rows_t;
-  int dbg;            // timing ablations (LDM_G3_DEBUG): 1 = no stores, 2 = no epilogue, 4 = no MFMA, 8 = no staging
+  const float* ln_cs; // EPI bit 6: column sums of the gamma-scaled weights (LayerNorm folded into the product)
+  float ln_eps;
+#ifdef LDM_TOOLS_BUILD
+  int dbg;            // timing ablations (tools build only): 1 = no stores, 2 = no epilogue, 4 = no MFMA, 8 = no staging
+#endif
 };
+
+// Timing ablations exist only in the tools build (make tools -> libldm_hip_tools.so, -DLDM_TOOLS_BUILD);
+// in the product library the tests below are the constant 0 and fold away.
+#ifdef LDM_TOOLS_BUILD
+#define LDM_G3_DBG(p) ((p).dbg)
+#else
+#define LDM_G3_DBG(p) 0
+#endif
 
 // Epilogue variant, a compile-time constant: a runtime "is there a bias / residual" test around
 // each epilogue load makes the compiler branch and drain the memory pipeline per load.
 //   bit 0 bias, bit 1 per-group addend, bit 2 residual, bits 3-4 activation (LDM_ACT_* code)
 //   bit 5 TRANSPOSED store per group of rows_t rows (the V projection lands directly in the
 //         attention kernel's V^T [sample][head dim][token]); plain product only
-constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4, kEpiTrans = 32;
+//   bit 6 LayerNorm of the A ROWS folded into the product (plain rows, K = the normalised width): the
+//         host passes W' = bf16(gamma (.) W), bias' = bias + W beta and ln_cs[n] = sum_k W'[n][k]; since
+//         LN(x) W^T = rstd (x W'^T - mean ln_cs) + bias', only the per-row mean / rstd are missing, and
+//         every wave derives those of ITS 64 rows from the A tiles that pass through LDS anyway during
+//         the workgroup's first n-tile (one row per lane, v_dot2c_f32_bf16 against (1, 1) and against
+//         itself): no LayerNorm launch, no normalised copy of the rows in HBM.  Statistics are f32
+//         sums of the bf16 values (E[x^2] - mean^2, clamped at 0)
+constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4, kEpiTrans = 32, kEpiLn = 64;
 constexpr int epi_code(bool bias, bool add, bool res, int act) { return (bias ? 1 : 0) | (add ? 2 : 0) | (res ? 4 : 0) | (act << 3); }
 
 // BN = 32 * TN columns per n-tile; waves 4 (M) x 2 (N); wave tile 64 x (16 TN)
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     char* dA = smem + stage * STAGE + wave * 1024;
     char* dB = dA + BM * 128;
     int kb;
-    if (p.dbg & 16) {            // timing ablation: no A staging at all (what a halo-staged A would approach)
+    if (LDM_G3_DBG(p) & 16) {            // timing ablation: no A staging at all (what a halo-staged A would approach)
       if constexpr (MODE != 0) { const int cc = kt / 9; const int tap = kt - cc * 9; kb = tap * p.Cin * ES + cc * 128; }
       else kb = kt * 128;
     } else if constexpr (MODE != 0) {
@@ -212,7 +231,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   }
 
   u32x4 fa[2][TM], fb[2][TN];
-  if (p.dbg & 32) {                                  // defined values for the no-read ablation
+  if (LDM_G3_DBG(p) & 32) {                                  // defined values for the no-read ablation
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
 #pragma unroll
@@ -222,7 +241,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     }
   }
   auto read_frags = [&](const char* cS) {
-    if (p.dbg & 32) return;                          // timing ablation: no LDS fragment reads
+    if (LDM_G3_DBG(p) & 32) return;                          // timing ablation: no LDS fragment reads
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
 #pragma unroll
@@ -238,7 +257,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   // the late half from the barrier on); sharing it evenly makes both finish together and leaves
   // the late half's fragment reads exposed at the end of the period.
   auto multiply = [&](int prio) {
-    if (p.dbg & 4) return;
+    if (LDM_G3_DBG(p) & 4) return;
     if (prio) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -257,15 +276,51 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     __builtin_amdgcn_s_setprio(0);
   };
 
+  // ---- LayerNorm fold: row statistics of this wave's 64 A rows (lane = row) -------------------
+  // All 8 physical 16-byte chunks of the row's K-tile are read (the XOR swizzle only permutes them),
+  // rotated by row >> 1 so that the 16 lanes one ds_read_b128 pass serves hit 16 different
+  // (row parity, chunk) bank groups.
+  [[maybe_unused]] float ln_s = 0.f, ln_q = 0.f;
+  [[maybe_unused]] auto ln_accum = [&](const char* cS) {
+    if constexpr ((EPI & kEpiLn) != 0) {
+      typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+      const int row = wm * WTM + lane;
+      const char* base = cS + row * 128;
+      const int rot = row >> 1;
+      const bf2 one = __builtin_bit_cast(bf2, 0x3f803f80u);
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const u32x4 c0 = *(const u32x4*)(base + (((j + rot) & 7) << 4));
+        const u32x4 c1 = *(const u32x4*)(base + (((j + 1 + rot) & 7) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bf2 a0 = __builtin_bit_cast(bf2, c0[e]), a1 = __builtin_bit_cast(bf2, c1[e]);
+          ln_s = __builtin_amdgcn_fdot2_f32_bf16(a0, one, ln_s, false);
+          ln_q = __builtin_amdgcn_fdot2_f32_bf16(a0, a0, ln_q, false);
+          ln_s = __builtin_amdgcn_fdot2_f32_bf16(a1, one, ln_s, false);
+          ln_q = __builtin_amdgcn_fdot2_f32_bf16(a1, a1, ln_q, false);
+        }
+      }
+    }
+  };
+
   // ---- register epilogue of one n-tile ----------------------------------------------------
   constexpr bool HB = (EPI & kEpiBias) != 0, HA = (EPI & kEpiAdd) != 0, HR = (EPI & kEpiRes) != 0;
-  constexpr int ACT = EPI >> 3;
+  constexpr int ACT = (EPI >> 3) & 3;
+  constexpr bool LN = (EPI & kEpiLn) != 0;
+  static_assert(!LN || (MODE == 0 && HB), "LayerNorm fold: plain rows, with the folded bias");
   constexpr bool GEGLU = ACT == LDM_ACT_GEGLU;
   static_assert(!GEGLU || TN == 4, "GEGLU: the wave tile must be one 64-row block of the interleaved weights");
   auto epilogue = [&](int tl) {
-    if (p.dbg & 2) return;
+    if (LDM_G3_DBG(p) & 2) return;
     const int n_w = (nt_begin + tl) * BN + wn * WTN;          // first column of this wave's tile
     const int g = lh;
+    [[maybe_unused]] float ln_mu = 0.f, ln_r = 0.f;           // of row wm * 64 + lane (sums complete after n-tile 0)
+    if constexpr (LN) {
+      const float ik = 1.0f / (float)p.K;
+      ln_mu = ln_s * ik;
+      ln_r = rsqrtf(fmaxf(ln_q * ik - ln_mu * ln_mu, 0.f) + p.ln_eps);
+    }
     if constexpr ((EPI & kEpiTrans) != 0) {
       // Transposed store: the lane owns column n = n_w + 16 j + (l & 15) and rows 16 i + 4 g + r.  Two
       // row blocks (i, i+1) are exchanged with v_permlane16_swap (8 consecutive rows = 16 bytes per
@@ -276,12 +331,32 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
 #pragma unroll
       for (int ip = 0; ip < TM; ip += 2) {
         const int mrow = m0 + wm * WTM + 16 * ip + 8 * pc;      // first of this lane's 8 rows (after the move)
-        const bool valid = mrow < p.M && !(p.dbg & 1);
+        const bool valid = mrow < p.M && !(LDM_G3_DBG(p) & 1);
         const int mc = valid ? mrow : 0;
         const int smp = mc / p.rows_t, tok = mc - smp * p.rows_t;
         bf16_t* obase = (bf16_t*)p.out_t + (int64_t)smp * p.stride_t + tok;
+        // LayerNorm fold: before the moves the lane owns column n_w + 16 j + (l & 15) and rows
+        // 16 i + 4 g + r; the rows' statistics live in the lanes of that number
+        [[maybe_unused]] float rmu[2][4], rrs[2][4];
+        if constexpr (LN) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              rmu[h][r] = __shfl(ln_mu, 16 * (ip + h) + 4 * g + r, 64);
+              rrs[h][r] = __shfl(ln_r, 16 * (ip + h) + 4 * g + r, 64);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
+          if constexpr (LN) {
+            const float cs = p.ln_cs[n_w + 16 * j + lr], bb = p.bias[n_w + 16 * j + lr];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+                acc[ip + h][j][r] = rrs[h][r] * (acc[ip + h][j][r] - rmu[h][r] * cs) + bb;
+          }
           const uint32_t x0 = pack_bf2(acc[ip][j][0], acc[ip][j][1]), x1 = pack_bf2(acc[ip][j][2], acc[ip][j][3]);
           const uint32_t y0 = pack_bf2(acc[ip + 1][j][0], acc[ip + 1][j][1]), y1 = pack_bf2(acc[ip + 1][j][2], acc[ip + 1][j][3]);
           const auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
@@ -303,6 +378,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
 #pragma unroll
       for (int j = 0; j < TN; ++j) bv[j] = *(const f32x4*)(p.bias + n_w + 16 * j + 4 * g);
     }
+    [[maybe_unused]] f32x4 csv[TN];                          // LayerNorm fold: column sums of this lane's columns
+    if constexpr (LN) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) csv[j] = *(const f32x4*)(p.ln_cs + n_w + 16 * j + 4 * g);
+    }
     constexpr int NOB = GEGLU ? TN / 2 : TN;                 // output blocks per row
     const int n_o = GEGLU ? (n_w >> 1) : n_w;                // first OUTPUT column of this wave's tile
 #pragma unroll
@@ -322,10 +402,19 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
 #pragma unroll
         for (int j = 0; j < NOB; ++j) rv[j] = *(const u32x2*)(rr + 16 * j);
       }
+      [[maybe_unused]] float mu_i = 0.f, rs_i = 0.f;         // statistics of row 16 i + lr: held by that lane
+      if constexpr (LN) {
+        mu_i = __shfl(ln_mu, 16 * i + lr, 64);
+        rs_i = __shfl(ln_r, 16 * i + lr, 64);
+      }
       // value of block j, registers r = 0..3 (columns n_w + 16 j + 4 g + r), before the residual
       auto block = [&](int j, float (&v)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+        if constexpr (LN) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = rs_i * (v[r] - mu_i * csv[j][r]);
+        }
         if constexpr (HB) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
@@ -381,7 +470,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       const int row2 = lane >> 2, pc = lane & 3;              // after the move: row inside the block, piece
       const int src = (16 * ((pc >> 1) | ((pc & 1) << 1)) + row2) * 4;   // piece 0..3 <- group 0, 2, 1, 3
       const int m2 = m0 + wm * WTM + 16 * i + row2;
-      const bool valid2 = m2 < p.M && !(p.dbg & 1);
+      const bool valid2 = m2 < p.M && !(LDM_G3_DBG(p) & 1);
       bf16_t* orow2 = (bf16_t*)p.out + (int64_t)(valid2 ? m2 : 0) * p.ldc + n_o;
 #pragma unroll
       for (int j = 0; j + 1 < NOB; j += 2) {
@@ -408,7 +497,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   // ---- pipeline ---------------------------------------------------------------------------
   int is_tl = 0, is_kt = 0;                          // next step to stage
   auto issue_next = [&](int stage) {
-    if (!(p.dbg & 8)) issue_tile(is_tl, is_kt, stage);
+    if (!(LDM_G3_DBG(p) & 8)) issue_tile(is_tl, is_kt, stage);
     if (++is_kt == nk) { is_kt = 0; ++is_tl; }
   };
   issue_next(0);
@@ -422,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   // half's epilogue runs beside the other half's MFMAs.  (Two loops, not one with `late` tests
   // inside: the merged loop keeps the fragments live across the epilogue and spills.)
   auto wait_step = [&](int s) {                      // this wave's LDS-DMAs of step s have landed
-    if (s + 1 < S && (p.dbg & 16)) {
+    if (s + 1 < S && (LDM_G3_DBG(p) & 16)) {
       if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LB - 1) : "memory");
     } else if (s + 1 < S) {
@@ -440,6 +529,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
       if (s + 2 < S) issue_next(sn);
       read_frags(smem + st * STAGE);
+      if constexpr (LN) { if (ctl == 0) ln_accum(smem + st * STAGE); }
       multiply(0);
       st = st + 1 == NSTAGE ? 0 : st + 1;
       if (++ck == nk) { ck = 0; ++ctl; }
@@ -453,6 +543,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
       if (s + 2 < S) issue_next(sn);
       read_frags(smem + st * STAGE);
+      if constexpr (LN) { if (ctl == 0) ln_accum(smem + st * STAGE); }
       st = st + 1 == NSTAGE ? 0 : st + 1;
       if (++ck == nk) { ck = 0; ++ctl; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

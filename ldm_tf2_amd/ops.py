@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -72,8 +73,9 @@ def workspace(device):
   launch to its reduce launch, in stream order, so one workspace serves one stream at a time:
   every model owns its own (`workspace_scope`, allocated at model build, before any graph
   capture); launches outside a model use one per (device, current stream)."""
-  if _WS_SCOPE:
-    return _WS_SCOPE[-1]
+  stack = _ws_stack()
+  if stack:
+    return stack[-1]
   key = (device, torch.cuda.current_stream(device).cuda_stream)
   ws = _WS.get(key)
   if ws is None:
@@ -86,22 +88,33 @@ def new_workspace(device):
   return torch.empty(_WS_BYTES, dtype=torch.uint8, device=device)
 
 
-_WS_SCOPE = []
+# The scope stacks (workspace, active plan table) are per host THREAD: two samplers driven from two
+# Python threads, one model each, must not see each other's workspace or plan table (the registry of
+# loaded tables, _TABLES, is shared and only read inside a forward).
+_TLS = threading.local()
+
+
+def _ws_stack():
+  st = getattr(_TLS, "ws", None)
+  if st is None:
+    st = _TLS.ws = []
+  return st
 
 
 class workspace_scope:
-  """`with workspace_scope(ws): ...` -- ldm_gemm launches inside use `ws` (a model's own
-  workspace), so two models replaying on different streams never share split-K slabs."""
+  """`with workspace_scope(ws): ...` -- ldm_gemm launches made by THIS thread inside use `ws` (a
+  model's own workspace), so two models replaying on different streams -- from one host thread or
+  from two -- never share split-K slabs."""
 
   def __init__(self, ws):
     self._ws = ws
 
   def __enter__(self):
-    _WS_SCOPE.append(self._ws)
+    _ws_stack().append(self._ws)
     return self
 
   def __exit__(self, *exc):
-    _WS_SCOPE.pop()
+    _ws_stack().pop()
     return False
 
 
@@ -120,9 +133,16 @@ class workspace_scope:
 # disables the packaged tables, LDM_GEMM_PLANS=<file> registers another.  Plans only reorder
 # float additions.
 _TABLES = {}          # (rows, latent, dtype code) -> {key: (tile, split_k)}
-_ACTIVE = {}          # the active table (possibly edited in place by tools/tune_step_plans.py)
-_ACTIVE_CFG = None
 _PLAN_RECORD = None
+
+
+def _active():
+  """This thread's active table (possibly edited in place by tools/tune_step_plans.py)."""
+  return getattr(_TLS, "active", None) or {}
+
+
+def _active_cfg():
+  return getattr(_TLS, "active_cfg", None)
 _TILE_DIMS = {1: (256, 128, 1), 2: (128, 128, 2), 3: (128, 64, 3), 4: (64, 64, 5), 6: (128, 160, 2),
               7: (256, 160, 1), 8: (128, 320, 1),       # BM, BN, resident workgroups per CU
               9: (256, 160, 1), 10: (128, 160, 2), 11: (256, 128, 1), 12: (128, 128, 2),   # bf16 16x16x32 MFMA path
@@ -179,11 +199,10 @@ def load_plans(path):
 def select_plans(rows=None, latent=None, dtype=None):
   """Makes the table of one step configuration the active one (none when no table is
   registered for it, or when called without arguments).  Returns the previous selection."""
-  global _ACTIVE, _ACTIVE_CFG
-  prev = _ACTIVE_CFG
+  prev = _active_cfg()
   ck = None if rows is None else _cfg_key(rows, latent, dtype)
-  _ACTIVE_CFG = ck
-  _ACTIVE = _TABLES.get(ck, {}) if ck is not None else {}
+  _TLS.active_cfg = ck
+  _TLS.active = _TABLES.get(ck, {}) if ck is not None else {}
   return prev
 
 
@@ -208,20 +227,21 @@ class plan_scope:
 def set_plan(key, plan):
   """Edits the ACTIVE table: plan = (tile, split_k) or None to drop the override
   (tools/tune_step_plans.py)."""
-  if _ACTIVE_CFG is None:
+  cfg = _active_cfg()
+  if cfg is None:
     raise RuntimeError("set_plan: no configuration selected (select_plans first)")
-  table = _TABLES.setdefault(_ACTIVE_CFG, {})
+  table = _TABLES.setdefault(cfg, {})
   if plan is None:
     table.pop(key, None)
   else:
     table[key] = (int(plan[0]), int(plan[1]))
-  select_plans(*_ACTIVE_CFG)
+  select_plans(*cfg)
 
 
 def gemm_plans(rows=None, latent=None, dtype=None):
   """Copy of one configuration's table (the active one by default)."""
   if rows is None:
-    return dict(_ACTIVE)
+    return dict(_active())
   return dict(_TABLES.get(_cfg_key(rows, latent, dtype), {}))
 
 
@@ -282,14 +302,18 @@ _load_default_plans()
 
 
 def resolve_plan(p: GemmParams):
-  """Applies the active plan table to an auto-planned problem (tile == 0 and split_k == 0)."""
-  if p.tile == 0 and p.split_k == 0 and not p.a_scale and not p.ln_out and (_ACTIVE or _PLAN_RECORD is not None):
+  """Applies the active plan table to an auto-planned problem (tile == 0 and split_k == 0); True if
+  the table supplied the plan."""
+  active = _active()
+  if p.tile == 0 and p.split_k == 0 and not p.a_scale and not p.ln_out and (active or _PLAN_RECORD is not None):
     key = plan_key(p)
     if _PLAN_RECORD is not None:
       _PLAN_RECORD[key] = (p.M, p.N, p.K, p.batch, p.act, p.dtype)
-    plan = _ACTIVE.get(key)
+    plan = active.get(key)
     if plan is not None:
       p.tile, p.split_k = plan
+      return True
+  return False
 
 
 def _gemm(p: GemmParams, device):
@@ -298,8 +322,16 @@ def _gemm(p: GemmParams, device):
   ws = workspace(device)
   p.workspace = ws.data_ptr()
   p.workspace_bytes = ws.numel()
-  resolve_plan(p)
-  check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
+  planned = resolve_plan(p)
+  st = lib.ldm_gemm(C.byref(p), _stream())
+  if st == _lib.ERR_ARG and planned:
+    # A plan key names the shape, not the epilogue: the table's persistent / halo tile exists only for
+    # the epilogue variants that are instantiated.  A launch that shares a key with a tuned one but not
+    # its epilogue (another U-Net configuration) runs on the cost model instead of failing.  Nothing
+    # was enqueued by the rejected call (argument checks precede every launch).
+    p.tile, p.split_k = 0, 0
+    st = lib.ldm_gemm(C.byref(p), _stream())
+  check(st, "ldm_gemm")
 
 
 def linear_ln_supported(n_out, dtype):
@@ -474,9 +506,6 @@ def conv3x3_small(x, kernel_hwio, bias, out):
   return out
 
 
-_GN_FUSED = os.environ.get("LDM_GN_NO_FUSED") is None
-
-
 def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None, fused=None):
   """x, out [B, H, W, C] (channel slices allowed).  Small images take the single-launch
   kernel (`fused`; default: whenever the library supports the shape), large ones the
@@ -484,7 +513,7 @@ def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None, fus
   B, C = x.shape[0], x.shape[-1]
   HW = x.numel() // (B * C)
   if fused is None:
-    fused = _GN_FUSED
+    fused = True
   if fused and lib.ldm_groupnorm_fused_supported(B, HW, C, groups, code(x.dtype)):
     assert out.dtype == x.dtype
     check(lib.ldm_groupnorm_fused(_ptr(x), row_ld(x), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),

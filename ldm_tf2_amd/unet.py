@@ -22,8 +22,6 @@ changes results beyond float rounding order):
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import layout as L
@@ -91,7 +89,8 @@ class UNet:
   def __init__(self, model_channels=320, out_channels=4, num_blocks=2,
                attention_resolutions=(4, 2, 1), dropout_rate=0.1, channel_mult=(1, 2, 4, 4),
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
-               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True):
+               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
+               split_qkv=True, small_conv_out=False):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -102,12 +101,13 @@ class UNet:
     # where its tile holds whole rows (C = 320).  Measured on MI355X at R=32: 11.02 vs 10.95 ms per
     # step -- the whole-row 128x320 tile (one workgroup per CU) plus the extra epilogue pass cost
     # slightly more than the 15 LayerNorm launches they replace.  Opt-in (parity-tested).
-    self._fuse_ln = bool(fuse_layernorm) or os.environ.get("LDM_FUSED_LN") is not None
+    self._fuse_ln = bool(fuse_layernorm)
     # fuse_qkv: the self-attention q|k and v projections as one GEMM launch with a transposed second
-    # output (ldm_gemm out2); LDM_NO_FUSED_QKV=1 is the A/B switch
-    self._fuse_qkv = bool(fuse_qkv) and os.environ.get("LDM_NO_FUSED_QKV") is None
-    # bf16: q|k and v as two persistent-kernel launches (v stored transposed); LDM_NO_SPLIT_QKV=1: A/B switch
-    self._split_qkv = dtype == torch.bfloat16 and os.environ.get("LDM_NO_SPLIT_QKV") is None
+    # output (ldm_gemm out2)
+    self._fuse_qkv = bool(fuse_qkv)
+    # bf16: q|k and v as two persistent-kernel launches (v stored transposed); split_qkv=False: A/B
+    self._split_qkv = dtype == torch.bfloat16 and bool(split_qkv)
+    self._small_conv_out = bool(small_conv_out)
     self._fuse_cache = {}
     self._model_channels = model_channels
     self._out_channels = out_channels
@@ -176,9 +176,9 @@ class UNet:
     self.conv_out = (L.vec(w["conv_out/kernel"], dev), L.vec(w["conv_out/bias"], dev))
     # bf16: the 320 -> 4 output conv as an implicit-GEMM launch too (N = 4 of a 64-column tile is
     # wasted MFMA work, but 3 GFLOP on the matrix cores beat the 8-lanes-per-pixel FMA kernel 4x);
-    # LDM_SMALL_CONV_OUT=1: the scalar kernel (A/B switch)
+    # small_conv_out=True: the scalar kernel (A/B)
     self.conv_out_mm = (L.conv_kernel(w["conv_out/kernel"], dt, dev)
-                        if dt == torch.bfloat16 and os.environ.get("LDM_SMALL_CONV_OUT") is None else None)
+                        if dt == torch.bfloat16 and not self._small_conv_out else None)
     # all ResBlock temb projections as ONE skinny Dense [sum(Cout), 4*mc]
     off, ks, bs = 0, [], []
     for r in res_all:
@@ -224,13 +224,20 @@ class UNet:
     key = ("gnconv", tuple(x.shape), x.stride(), tuple(out.shape), out.stride())
     fused = self._fuse_cache.get(key)
     if fused is None:
-      fused = self.fuse_groupnorm and ops.conv3x3_prologue_supported(x, conv[0], out)
+      # fused = the halo tile to launch on: 0 = the library's own choice (only shapes that fill the
+      # chip), 21..23 = forced (fuse_groupnorm="force": every eligible shape, tests on tiny models)
+      fused = False
+      if self.fuse_groupnorm == "force":
+        fused = next((t for t in (21, 22, 23) if ops.conv3x3_prologue_supported(x, conv[0], out, tile=t)), False)
+      elif self.fuse_groupnorm and ops.conv3x3_prologue_supported(x, conv[0], out):
+        fused = True
       self._fuse_cache[key] = fused
     if fused:
       sc = B_.get("gn_scale", (R, cin), torch.float32)
       sh = B_.get("gn_shift", (R, cin), torch.float32)
       ops.groupnorm_scale_shift(x, gn[0], gn[1], sc, sh, GN_EPS_RES, partial=self._gnp)
-      return ops.conv3x3(x, conv[0], out, bias=conv[1], a_scale=sc, a_shift=sh, a_silu=True, **kw)
+      return ops.conv3x3(x, conv[0], out, bias=conv[1], a_scale=sc, a_shift=sh, a_silu=True,
+                         tile=0 if fused is True else fused, **kw)
     t0 = B_.get("gn", tuple(x.shape), dt)
     ops.groupnorm(x, gn[0], gn[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
     return ops.conv3x3(t0, conv[0], out, bias=conv[1], **kw)

@@ -104,9 +104,39 @@ def _converter_functions():
   want = {"get_transformer_weights", "get_unet_weights", "get_decoder_weights", "get_encoder_weights"}
   fns = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in want]
   assert {f.name for f in fns} == want
-  ns = {}
-  exec(compile(ast.Module(body=fns, type_ignores=[]), REF, "exec"), ns)      # only these four defs run
+  for f in fns:
+    _vet(f)
+  # only these four (vetted) defs run, and with two builtins: the reference tree is untrusted content
+  ns = {"__builtins__": {"range": range, "str": str}}
+  exec(compile(ast.Module(body=fns, type_ignores=[]), REF, "exec"), ns)
   return ns
+
+
+# What the four list-building functions are made of (checked before anything of them executes): plain
+# data flow -- loops, subscripts, list.append, the four layout transforms -- and nothing that could
+# reach outside: no imports, no attribute other than the transforms, no call other than range / str /
+# the functions' own nested helpers, no decorators, no default arguments, no dunder names.
+_NODES = {"Add", "Assign", "Attribute", "BinOp", "Call", "Compare", "Constant", "Continue", "Dict", "Eq", "Expr",
+          "For", "FormattedValue", "FunctionDef", "If", "In", "JoinedStr", "List", "Load", "Mult", "Name", "Return",
+          "Store", "Subscript", "Tuple", "USub", "UnaryOp", "arg", "arguments", "Sub", "NotEq", "NotIn", "Lt", "Gt",
+          "LtE", "GtE", "And", "Or", "BoolOp", "Not", "Slice", "AugAssign", "Pass", "Break"}
+_ATTRS = {"append", "extend", "transpose", "T", "reshape", "squeeze"}
+
+
+def _vet(fn):
+  local_defs = {n.name for n in ast.walk(fn) if isinstance(n, ast.FunctionDef)}
+  for n in ast.walk(fn):
+    kind = type(n).__name__
+    assert kind in _NODES, f"{fn.name}: unexpected construct {kind} (line {getattr(n, 'lineno', '?')})"
+    if isinstance(n, ast.FunctionDef):
+      assert not n.decorator_list and not n.args.defaults and not n.args.kw_defaults and \
+          n.args.vararg is None and n.args.kwarg is None, f"{fn.name}: decorators / defaults in {n.name}"
+    if isinstance(n, ast.Attribute):
+      assert n.attr in _ATTRS, f"{fn.name}: attribute .{n.attr}"
+    if isinstance(n, ast.Name):
+      assert not n.id.startswith("__"), f"{fn.name}: name {n.id}"
+    if isinstance(n, ast.Call) and isinstance(n.func, ast.Name):
+      assert n.func.id in {"range", "str"} | local_defs, f"{fn.name}: call to {n.func.id}"
 
 
 def _recorded(fn, rules, manifest):

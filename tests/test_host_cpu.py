@@ -217,3 +217,17 @@ def test_sharded_sampling_and_all_gather_over_gloo(tmp_path):
                      capture_output=True, text=True, timeout=240, env=env)
   assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
   assert "GLOO_OK" in r.stdout
+
+
+def test_product_library_reads_no_environment_switch():
+  """VERDICT r2 #7 / ADVICE: the timing ablations (LDM_G3_DEBUG) and tile A/B switches exist only in
+  the tools build (`make tools`, -DLDM_TOOLS_BUILD).  The shipped library neither names an LDM_*
+  variable nor imports getenv: no environment variable can change what it computes."""
+  from ldm_tf2_amd import _lib
+  data = open(_lib.LIB_PATH, "rb").read()
+  import re
+  names = set(re.findall(rb"LDM_[A-Z0-9_]{3,}", data))
+  assert not names, f"environment-switch-like strings in {_lib.LIB_PATH}: {sorted(names)[:5]}"
+  r = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True)
+  if r.returncode == 0:
+    assert "getenv" not in r.stdout.split(), "libldm_hip.so imports getenv"

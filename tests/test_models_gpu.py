@@ -21,6 +21,10 @@ from ldm_tf2_amd import weights as Wt  # noqa: E402
 from oracle import ldm_oracle as O  # noqa: E402
 
 REL = {torch.float32: 5e-5, torch.bfloat16: 4e-2}
+# free-running 10-step loops (x_0 latents, images, progressive frames): 2x the error measured on
+# MI355X (f32: 5.0e-6 / 6.2e-6 / 6.3e-6 for eta = 0 / 1 / progressive -- no larger than ONE U-Net
+# evaluation's, the trajectory does not amplify; bf16: 3.0e-2 / 4.0e-2), no free factor
+LOOP_REL = {torch.float32: 1.3e-5, torch.bfloat16: 8e-2}
 DT = [torch.float32, torch.bfloat16]
 
 UNET_CFG = dict(model_channels=64, out_channels=4, num_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8)
@@ -40,10 +44,11 @@ def rel_err(got, ref):
   return ((got - ref).norm() / ref.norm()).item(), (got - ref).abs().max().item()
 
 
-def check(got, ref, dtype, what, factor=1.0):
+def check(got, ref, dtype, what, gate=None):
   r, m = rel_err(got, ref)
   print(f"{what} [{dtype}]: rel={r:.3e} maxabs={m:.3e}")
-  assert r < REL[dtype] * factor, f"{what}: rel err {r:.3e} (max abs {m:.3e})"
+  gate = REL[dtype] if gate is None else gate
+  assert r < gate, f"{what}: rel err {r:.3e} >= {gate:.1e} (max abs {m:.3e})"
 
 
 @pytest.fixture(scope="module")
@@ -85,14 +90,14 @@ def test_unet_forward(dev, dtype, unet_w):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_unet_forward_fused_groupnorm(dev, dtype, unet_w, monkeypatch):
+def test_unet_forward_fused_groupnorm(dev, dtype, unet_w):
   """GroupNorm+SiLU folded into the halo-staged conv (opt-in path) gives the same U-Net."""
   from ldm_tf2_amd.unet import UNet
-  monkeypatch.setenv("LDM_HALO_MIN_TILES", "1")     # let the tiny shapes take the halo path
   x, ctx = _inputs()
   t = np.array([981, 981, 21, 500], dtype=np.int32)
   ref = O.unet_forward(x, t, ctx, unet_w)
-  unet = UNet(**UNET_CFG, weights=unet_w, dtype=dtype, device=dev, context_dim=CTX_DIM, fuse_groupnorm=True)
+  unet = UNet(**UNET_CFG, weights=unet_w, dtype=dtype, device=dev, context_dim=CTX_DIM,
+              fuse_groupnorm="force")       # forced halo tiles: the tiny shapes take the path too
   got = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
   assert any(unet._fuse_cache.values()), "no conv took the fused path"
   check(got, ref, dtype, "unet (fused GroupNorm)")
@@ -227,8 +232,8 @@ def test_ddim_loop_end_to_end(dev, dtype, eta, unet_w, txt_w, kl_w):
   s = _build_sampler(dev, dtype, unet_w, txt_w, kl_w, ldm=ldm, use_graph=True)
   got = s.ddim_p_sample_loop(ids, [B, 16, 16, 4], guidance_scale=5., x_T=x_T, noises=noises)
   assert tuple(got.shape) == (B, 128, 128, 3)
-  check(s._xt, rec[-1], dtype, "x_0 latents", factor=5.0)
-  check(got, ref, dtype, "images", factor=5.0)
+  check(s._xt, rec[-1], dtype, "x_0 latents", gate=LOOP_REL[dtype])
+  check(got, ref, dtype, "images", gate=LOOP_REL[dtype])
   # eager (no graph) path gives bit-identical results to graph replay
   s2 = _build_sampler(dev, dtype, unet_w, txt_w, kl_w, ldm=ldm, use_graph=False)
   rec2 = []
@@ -253,9 +258,9 @@ def test_progressive_sampling(dev, unet_w, txt_w, kl_w):
   s = _build_sampler(dev, torch.float32, unet_w, txt_w, kl_w, ldm=ldm)
   gi, gs, gx = s.ddim_p_sample_loop_progressive(ids, [B, 16, 16, 4], 5., record_freq=freq, x_T=x_T, noises=noises)
   assert tuple(gs.shape) == (B, n // freq, 128, 128, 3) and tuple(gx.shape) == tuple(gs.shape)
-  check(gi, ri, torch.float32, "progressive: images", factor=5.0)
-  check(gs, rs, torch.float32, "progressive: samples", factor=5.0)
-  check(gx, rx, torch.float32, "progressive: pred_x0", factor=5.0)
+  check(gi, ri, torch.float32, "progressive: images", gate=LOOP_REL[torch.float32])
+  check(gs, rs, torch.float32, "progressive: samples", gate=LOOP_REL[torch.float32])
+  check(gx, rx, torch.float32, "progressive: pred_x0", gate=LOOP_REL[torch.float32])
   # the final images equal the plain loop's
   plain = s.ddim_p_sample_loop(ids, [B, 16, 16, 4], 5., x_T=x_T, noises=noises)
   assert rel_err(plain, gi.cpu())[0] < 1e-5

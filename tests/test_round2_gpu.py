@@ -211,6 +211,14 @@ def test_progressive_sampler_at_full_size_chunks_the_decode(dev):
   whole = ae.decode(lat, scale_factor=0.18215)
   part = ae.decode(lat[30:33], scale_factor=0.18215)
   assert rel(whole[30:33], part.cpu()) < 2e-2
+  # the float32 twin of the same comparison: chunking only changes which tiles (i.e. which summation
+  # order) a frame meets, so in f32 the chunked and the stand-alone decode agree to rounding
+  ae32 = AutoencoderKL(**kcfg, dtype=torch.float32, device=dev)
+  whole32 = ae32.decode(lat, scale_factor=0.18215)
+  part32 = ae32.decode(lat[30:33], scale_factor=0.18215)
+  r32 = rel(whole32[30:33], part32.cpu())
+  print(f"chunked vs stand-alone decode, f32: rel={r32:.3e}")
+  assert r32 < 1e-5
 
 
 def test_two_samplers_on_two_streams_do_not_share_workspaces(dev):

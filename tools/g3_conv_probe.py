@@ -2,6 +2,7 @@
 """Timing of the persistent kernel (tile 13) on one conv; LDM_G3_DEBUG ablations per process."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.toolslib  # noqa: F401  (ablations live in the tools build only)
 from ldm_tf2_amd import ops
 from tools.gemm_bench import time_fn
 R, hw, cin, cout, tile = (int(v) for v in sys.argv[1:6])

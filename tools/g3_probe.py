@@ -3,6 +3,7 @@
 per process, so run one process per variant."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tools.toolslib  # noqa: F401  (ablations live in the tools build only)
 from ldm_tf2_amd import ops
 from tools.gemm_bench import time_fn
 M, K, N, tile = (int(v) for v in sys.argv[1:5])

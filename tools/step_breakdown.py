@@ -2,7 +2,7 @@
 """Where one U-Net step spends its time, per ldm_gemm problem (in situ).
 
 Runs the full-size U-Net step eagerly with every ldm_gemm launch bracketed by HIP events
-(ops.set_gemm_timer) and groups the brackets by problem key: launches per step, total
+(tools.gemm_hooks.time_gemms) and groups the brackets by problem key: launches per step, total
 microseconds, algorithmic TFLOP/s and the (tile, split) the launch used.  Brackets add
 ~1-2 us per launch, so small launches read a little slow; the ranking is what matters.
 
