@@ -143,9 +143,45 @@ typedef struct {
   void* out2;
   int64_t ld2, stride2;
   int32_t n_split, rows2;
+  /* LayerNormalization of the A ROWS folded into the product (unet.py:309-313: LN -> q|k / v / q /
+   * GEGLU projections).  With w = bf16(gamma (.) W), bias = b + W beta and ln_cs[n] = sum_k w[n][k]
+   * (all prepared by the host, float32 [N], 16-byte aligned),
+   *     LN(a) W^T + b  =  rstd_m * (sum_k a[m][k] w[n][k]  -  mean_m * ln_cs[n]) + bias[n],
+   * and the kernel derives mean_m / rstd_m (eps = ln_eps, biased variance over the K columns) from
+   * the A tiles it stages anyway: no LayerNorm launch, no normalised copy of the rows.  bf16 plain
+   * rows (conv = 0), batch 1, persistent tiles 13 / 14 (chosen automatically), epilogues: bias,
+   * bias + GEGLU, or the transposed store (out2 with n_split = 0).  NULL = off. */
+  const float* ln_cs;
+  /* Split-K only: 1 = leave the float32 partial slabs in `workspace` and do NOT launch the reduce.  The
+   * caller completes the product later, on the same stream and with the SAME parameters, either with
+   * ldm_gemm_reduce (the plain reduce + epilogue) or with ldm_groupnorm_splitk (reduce + epilogue +
+   * the GroupNormalization that follows, one launch).  Ignored when the plan does not split K
+   * (ldm_gemm_splits tells: the product is then complete when ldm_gemm returns). */
+  int32_t defer_reduce;
 } ldm_gemm_params;
 
 int ldm_gemm(const ldm_gemm_params* p, void* stream);
+/* number of K slabs ldm_gemm writes for these parameters (1 = no split-K; host only) */
+int ldm_gemm_splits(const ldm_gemm_params* p);
+/* completes a product whose reduce was deferred (defer_reduce = 1): slabs -> bias / addend /
+ * activation / residual -> out.  Same parameters as the ldm_gemm call. */
+int ldm_gemm_reduce(const ldm_gemm_params* p, void* stream);
+/*
+ * Completes a deferred split-K product AND applies the GroupNormalization (+SiLU) that consumes it
+ * (unet.py:383-392: conv -> GroupNorm -> SiLU -> conv), in ONE launch: a workgroup owns whole
+ * groups of one sample, sums the slabs of its [HW][channels] slab (+ bias / per-sample addend /
+ * residual, in the order of the plain reduce: the stored value is bit-identical), keeps the values
+ * ROUNDED to the output dtype in registers, writes them to p->out when `store_out` (skip it when
+ * nothing else reads the product: conv1 of a ResBlock) and writes GroupNorm(+SiLU) of them to
+ * gn_out (pixel stride ld_gn, dtype of p->out).  p: the parameters of the deferred ldm_gemm call
+ * (M = B*HW rows, N = C channels, row-major output, no activation, batch 1).  Shapes:
+ * ldm_groupnorm_splitk_supported(B, HW, C, groups, out dtype).
+ */
+/* 1 if ldm_groupnorm_splitk supports this shape (host query; a subset of ldm_groupnorm_fused's) */
+int ldm_groupnorm_splitk_supported(int B, int HW, int C, int groups, int dtype);
+int ldm_groupnorm_splitk(const ldm_gemm_params* p, const float* gamma, const float* beta, void* gn_out,
+                         int64_t ld_gn, int B, int HW, int groups, float eps, int silu, int store_out,
+                         void* stream);
 /* 1 if ldm_gemm accepts ln_out for a [M][N] output of this dtype (host query) */
 int ldm_gemm_ln_supported(int N, int dtype);
 /* the tile configuration and split-K factor ldm_gemm would pick for these params (host only;

@@ -38,6 +38,7 @@ class GemmParams(C.Structure):
       ("a_scale", c_vp), ("a_shift", c_vp), ("a_silu", c_i32), ("no_lead_pad", c_i32),
       ("ln_out", c_vp), ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ld_ln", c_i64), ("ln_eps", c_f32),
       ("out2", c_vp), ("ld2", c_i64), ("stride2", c_i64), ("n_split", c_i32), ("rows2", c_i32),
+      ("ln_cs", c_vp), ("defer_reduce", c_i32),
   ]
 
 
@@ -47,6 +48,11 @@ SIGNATURES = {
     "ldm_last_error": (c_i32, [C.c_char_p, c_i32]),
     "ldm_gemm": (c_i32, [C.POINTER(GemmParams), c_vp]),
     "ldm_gemm_workspace_bytes": (c_sz, [C.POINTER(GemmParams)]),
+    "ldm_gemm_splits": (c_i32, [C.POINTER(GemmParams)]),
+    "ldm_gemm_reduce": (c_i32, [C.POINTER(GemmParams), c_vp]),
+    "ldm_groupnorm_splitk_supported": (c_i32, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "ldm_groupnorm_splitk": (c_i32, [C.POINTER(GemmParams), c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32,
+                                     c_i32, c_i32, c_vp]),
     "ldm_conv3x3_small": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_i32,
                                   c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "ldm_groupnorm_nchunks": (c_i32, [c_i32, c_i32, c_i32]),

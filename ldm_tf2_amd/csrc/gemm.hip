@@ -253,12 +253,104 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   *split_out = best_split;
 }
 
+// The (tile, split) ldm_gemm really launches for p: the cost model / forced plan of choose() plus the
+// overrides of the launch forms that pin the tile, and the split as it comes out after whole K-tile
+// ranges (empty trailing splits dropped).  One function, because ldm_gemm, ldm_gemm_splits,
+// ldm_gemm_reduce and ldm_groupnorm_splitk must agree on the slab count.
+void final_plan(const ldm_gemm_params* p, int* cfg_out, int* split_out, int* kps_out) {
+  const int esize = p->dtype == LDM_BF16 ? 2 : 4;
+  int cfg, split;
+  choose(p, esize, &cfg, &split);
+  if (p->ln_out) { cfg = kLnTile; split = 1; }
+  if (p->ln_cs && !is_persistent(cfg)) {
+    // LayerNorm fold: the persistent kernel only (it derives the row statistics from its A tiles)
+    cfg = (p->act == LDM_ACT_GEGLU || p->N % 160 != 0) ? 14 : (p->N % 128 == 0 && p->tile != 13 ? 14 : 13);
+    split = 1;
+  }
+  if (p->out2 && !is_persistent(cfg)) split = 1;
+  if (is_persistent(cfg)) split = 1;
+  const int ktiles = cdiv(p->K, 128 / esize);
+  int kps = cdiv(ktiles, split < 1 ? 1 : split);
+  if (is_halo_ring(cfg)) kps = cdiv(kps, 9) * 9;   // splits at whole channel chunks (9 taps)
+  split = cdiv(ktiles, kps);                        // drop empty trailing splits
+  *cfg_out = cfg; *split_out = split; *kps_out = kps;
+}
+
+// kernel arguments of the non-persistent path (main kernel and split-K reduce alike)
+void build_args(const ldm_gemm_params* p, int cfg, int split, int kps, GemmArgs* out) {
+  const int esize = p->dtype == LDM_BF16 ? 2 : 4;
+  const int bke = 128 / esize;
+  int64_t a_bytes;
+  if (p->conv) a_bytes = (((int64_t)p->B * p->H * p->W - 1) * p->lda + p->Cin) * esize;
+  else a_bytes = (((int64_t)p->M - 1) * p->lda + p->K) * esize;
+  const int64_t w_bytes = (int64_t)p->N * p->K * esize;
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.a = (const char*)p->a; a.w = (const char*)p->w; a.bias = p->bias; a.addend = p->addend;
+  a.residual = (const char*)p->residual; a.out = (char*)p->out; a.ws = (float*)p->workspace;
+  a.lda = p->lda; a.ldr = p->ldr; a.ldc_m = p->ldc_m; a.ldc_n = p->ldc_n;
+  a.stride_a = p->stride_a; a.stride_w = p->stride_w; a.stride_c = p->stride_c; a.stride_r = p->stride_r;
+  a.add_ld = p->add_ld; a.M = p->M; a.N = p->N; a.K = p->K; a.batch = p->batch;
+  a.a_bytes = (uint32_t)a_bytes; a.w_bytes = (uint32_t)w_bytes;
+  a.add_rows = p->add_rows > 0 ? p->add_rows : 1;
+  a.conv = p->conv; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.OH = p->OH; a.OW = p->OW;
+  a.stride = p->stride; a.upsample = p->upsample; a.pad = p->no_lead_pad ? 0 : 1; a.act = p->act; a.out_dtype = p->out_dtype;
+  a.alpha = p->alpha;
+  a.ln_out = (char*)p->ln_out; a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_beta; a.ld_ln = p->ld_ln;
+  a.ln_eps = p->ln_eps;
+  a.out2 = (char*)p->out2; a.ld2 = p->ld2; a.stride2 = p->stride2; a.n_split = p->n_split; a.rows2 = p->rows2;
+  // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
+  const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
+  auto al = [](const void* q, int by) { return ((uintptr_t)q % by) == 0; };
+  a.vec_epilogue =
+      p->ldc_n == 1 && nout % 8 == 0 && p->ldc_m % 8 == 0 && p->stride_c % 8 == 0 && al(p->out, 16) &&
+      (!p->residual || (p->ldr % 8 == 0 && p->stride_r % 8 == 0 && al(p->residual, 16))) &&
+      (!p->bias || al(p->bias, 16)) &&
+      (!p->addend || (al(p->addend, 16) && p->add_ld % 4 == 0));
+  a.ktiles = cdiv(p->K, bke);
+  a.split_k = split;
+  a.ktiles_per_split = kps;
+  const TileCfg t = kTiles[cfg];
+  a.tiles_m = cdiv(p->M, t.bm);
+  a.tiles_n = cdiv(p->N, t.bn);
+  *out = a;
+}
+
+int launch_reduce(const ldm_gemm_params* p, const GemmArgs& a, hipStream_t s) {
+  const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
+  const bool vec = a.vec_epilogue && ((uintptr_t)p->workspace % 16) == 0 && p->N % 4 == 0;
+  int64_t total = vec ? (int64_t)p->M * (nout / 8) : (int64_t)p->M * nout;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  if (vec) hipLaunchKernelGGL(splitk_epilogue_vec_kernel, dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a);
+  return ldm_launch_status("ldm_gemm(splitk epilogue)");
+}
+
 }  // namespace
+
+extern "C" int ldm_gemm_splits(const ldm_gemm_params* p) {
+  if (!p || !(p->dtype == LDM_F32 || p->dtype == LDM_BF16) || p->K <= 0) return 0;
+  int cfg, split, kps;
+  final_plan(p, &cfg, &split, &kps);
+  return split;
+}
+
+extern "C" int ldm_gemm_reduce(const ldm_gemm_params* p, void* stream) {
+  LDM_CHECK_ARG(p && p->out && p->workspace, "ldm_gemm_reduce: null pointer");
+  int cfg, split, kps;
+  final_plan(p, &cfg, &split, &kps);
+  LDM_CHECK_ARG(split > 1, "ldm_gemm_reduce: these parameters do not split K (nothing was deferred)");
+  LDM_CHECK_ARG(p->workspace_bytes >= (size_t)split * p->M * p->N * 4, "ldm_gemm_reduce: workspace too small");
+  GemmArgs a;
+  build_args(p, cfg, split, kps, &a);
+  return launch_reduce(p, a, (hipStream_t)stream);
+}
 
 extern "C" size_t ldm_gemm_workspace_bytes(const ldm_gemm_params* p) {
   if (!p) return 0;
-  int cfg, split;
-  choose(p, p->dtype == LDM_BF16 ? 2 : 4, &cfg, &split);
+  int cfg, split, kps;
+  final_plan(p, &cfg, &split, &kps);
   return split > 1 ? (size_t)split * p->M * p->N * 4 : 0;
 }
 
@@ -269,7 +361,8 @@ extern "C" int ldm_gemm_ln_supported(int N, int dtype) {
 extern "C" int ldm_gemm_plan(const ldm_gemm_params* p, int* tile, int* split_k) {
   LDM_CHECK_ARG(p && tile && split_k, "ldm_gemm_plan: null pointer");
   LDM_CHECK_ARG(p->dtype == LDM_F32 || p->dtype == LDM_BF16, "ldm_gemm_plan: bad dtype %d", p->dtype);
-  choose(p, p->dtype == LDM_BF16 ? 2 : 4, tile, split_k);
+  int kps;
+  final_plan(p, tile, split_k, &kps);
   return LDM_OK;
 }
 
@@ -326,19 +419,19 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     if (r == 1) return LDM_OK;
     if (r < 0) return r;
   }
+  LDM_CHECK_ARG(!p->ln_cs || (p->dtype == LDM_BF16 && p->out_dtype == LDM_BF16 && !p->conv && p->batch == 1 && !p->ln_out),
+                "ldm_gemm: ln_cs (LayerNorm fold) needs bf16 plain rows, batch 1 (persistent tiles 13 / 14)");
   LDM_CHECK_ARG(!p->a_scale, "ldm_gemm: the a_scale/a_shift prologue needs the stride-1 halo conv path "
                              "(shape not eligible: use ldm_groupnorm_apply + a plain conv)");
 
-  int cfg, split;
-  choose(p, esize, &cfg, &split);
+  int cfg, split, kps;
+  final_plan(p, &cfg, &split, &kps);
   if (p->ln_out) {
     LDM_CHECK_ARG(!p->conv && p->batch == 1 && p->act != LDM_ACT_GEGLU && p->ldc_n == 1 &&
                       ldm_gemm_ln_supported(p->N, p->out_dtype) && p->ln_gamma && p->ln_beta,
                   "ldm_gemm: ln_out needs plain rows, batch 1, no GEGLU, N == %d and gamma/beta", kTiles[kLnTile].bn);
     LDM_CHECK_ARG(p->ld_ln % 8 == 0 && ((uintptr_t)p->ln_out % 16) == 0 && ((uintptr_t)p->ln_gamma % 16) == 0 &&
                       ((uintptr_t)p->ln_beta % 16) == 0, "ldm_gemm: ln_out / gamma / beta alignment");
-    cfg = kLnTile;
-    split = 1;
   }
   if (p->out2 && !is_persistent(cfg)) {
     LDM_CHECK_ARG(!p->conv && p->batch == 1 && p->act != LDM_ACT_GEGLU && p->ldc_n == 1 && !p->ln_out && !p->residual,
@@ -347,7 +440,6 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
                   "ldm_gemm: n_split=%d must be a multiple of the tile width %d", p->n_split, kTiles[cfg].bn);
     LDM_CHECK_ARG(p->rows2 > 0 && p->rows2 % 4 == 0 && p->M % p->rows2 == 0 && p->ld2 % 4 == 0 && p->stride2 % 4 == 0 &&
                       ((uintptr_t)p->out2 % 16) == 0, "ldm_gemm: out2 geometry (rows2 %% 4, M %% rows2, ld2 / stride2 %% 4, alignment)");
-    split = 1;
   }
   if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5 || cfg == 11 || cfg == 12 || cfg == 14, "ldm_gemm: GEGLU needs a tile whose width is a multiple of 64 (1, 2, 5, 11, 12)");
   LDM_CHECK_ARG(!kBf16Only[cfg] || esize == 2, "ldm_gemm: tile %d is bf16 only", cfg);
@@ -361,8 +453,12 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
     // out2 with n_split == 0: the WHOLE product is stored transposed per group of rows2 rows (V^T)
     const bool trans = p->out2 != nullptr;
+    const bool ln = p->ln_cs != nullptr;
+    if (ln)
+      LDM_CHECK_ARG(!p->conv && p->bias && al16(p->ln_cs) && p->ln_eps > 0.f && !p->addend && !p->residual,
+                    "ldm_gemm: ln_cs (LayerNorm fold) needs plain rows, the folded bias, ln_eps > 0 and no addend / residual");
     if (trans)
-      LDM_CHECK_ARG(p->n_split == 0 && !p->conv && !p->bias && !p->addend && !p->residual && p->act == LDM_ACT_NONE &&
+      LDM_CHECK_ARG(p->n_split == 0 && !p->conv && (!p->bias || ln) && !p->addend && !p->residual && p->act == LDM_ACT_NONE &&
                         p->rows2 > 0 && p->rows2 % 32 == 0 && p->M % p->rows2 == 0 && p->ld2 % 8 == 0 && p->stride2 % 8 == 0 &&
                         al16(p->out2),
                     "ldm_gemm: tile %d transposed output needs n_split 0, a plain product, rows2 %% 32 == 0, ld2 / stride2 %% 8 == 0", cfg);
@@ -398,9 +494,12 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     dim3 grid3((unsigned)(g.panels * g.nsplit));
     hipStream_t s3 = (hipStream_t)stream;
     g.out_t = (char*)p->out2; g.ld_t = p->ld2; g.stride_t = p->stride2; g.rows_t = p->rows2;
-    const int epi = trans ? kEpiTrans : epi_code(p->bias != nullptr, p->addend != nullptr, p->residual != nullptr, p->act);
+    g.ln_cs = p->ln_cs; g.ln_eps = p->ln_eps;
+    const int epi = (trans ? (ln ? (kEpiTrans | kEpiBias) : kEpiTrans)
+                           : epi_code(p->bias != nullptr, p->addend != nullptr, p->residual != nullptr, p->act)) | (ln ? kEpiLn : 0);
     bool ok;
-    if (!p->conv) ok = launch_gemm3<0>(bn / 32, epi, g, grid3, s3);
+    if (ln) ok = launch_gemm3_ln(bn / 32, epi, g, grid3, s3);
+    else if (!p->conv) ok = launch_gemm3<0>(bn / 32, epi, g, grid3, s3);
     else if (!p->upsample) ok = launch_gemm3<1>(bn / 32, epi, g, grid3, s3);
     else ok = launch_gemm3<2>(bn / 32, epi, g, grid3, s3);
     LDM_CHECK_ARG(ok, "ldm_gemm: tile %d (persistent) has no kernel for this epilogue (bias %d addend %d residual %d act %d)",
@@ -408,35 +507,8 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     return ldm_launch_status("ldm_gemm(persistent)");
   }
   GemmArgs a;
-  memset(&a, 0, sizeof(a));
-  a.a = (const char*)p->a; a.w = (const char*)p->w; a.bias = p->bias; a.addend = p->addend;
-  a.residual = (const char*)p->residual; a.out = (char*)p->out; a.ws = (float*)p->workspace;
-  a.lda = p->lda; a.ldr = p->ldr; a.ldc_m = p->ldc_m; a.ldc_n = p->ldc_n;
-  a.stride_a = p->stride_a; a.stride_w = p->stride_w; a.stride_c = p->stride_c; a.stride_r = p->stride_r;
-  a.add_ld = p->add_ld; a.M = p->M; a.N = p->N; a.K = p->K; a.batch = p->batch;
-  a.a_bytes = (uint32_t)a_bytes; a.w_bytes = (uint32_t)w_bytes;
-  a.add_rows = p->add_rows > 0 ? p->add_rows : 1;
-  a.conv = p->conv; a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.OH = p->OH; a.OW = p->OW;
-  a.stride = p->stride; a.upsample = p->upsample; a.pad = p->no_lead_pad ? 0 : 1; a.act = p->act; a.out_dtype = p->out_dtype;
-  a.alpha = p->alpha;
-  a.ln_out = (char*)p->ln_out; a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_beta; a.ld_ln = p->ld_ln;
-  a.ln_eps = p->ln_eps;
-  a.out2 = (char*)p->out2; a.ld2 = p->ld2; a.stride2 = p->stride2; a.n_split = p->n_split; a.rows2 = p->rows2;
-  // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
-  const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
-  auto al = [](const void* q, int by) { return ((uintptr_t)q % by) == 0; };
-  a.vec_epilogue =
-      p->ldc_n == 1 && nout % 8 == 0 && p->ldc_m % 8 == 0 && p->stride_c % 8 == 0 && al(p->out, 16) &&
-      (!p->residual || (p->ldr % 8 == 0 && p->stride_r % 8 == 0 && al(p->residual, 16))) &&
-      (!p->bias || al(p->bias, 16)) &&
-      (!p->addend || (al(p->addend, 16) && p->add_ld % 4 == 0));
+  build_args(p, cfg, split, kps, &a);
   if (p->ln_out) LDM_CHECK_ARG(a.vec_epilogue, "ldm_gemm: ln_out needs the 16-byte-aligned row-major epilogue");
-  a.ktiles = cdiv(p->K, bke);
-  a.split_k = split;
-  a.ktiles_per_split = cdiv(a.ktiles, split);
-  if (is_halo_ring(cfg)) a.ktiles_per_split = cdiv(a.ktiles_per_split, 9) * 9;   // splits at whole channel chunks (9 taps)
-  // drop empty trailing splits
-  a.split_k = split = cdiv(a.ktiles, a.ktiles_per_split);
   if (split > 1) {
     const size_t need = (size_t)split * p->M * p->N * 4;
     if (!p->workspace || p->workspace_bytes < need) {
@@ -445,9 +517,6 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
       return LDM_ERR_WORKSPACE;
     }
   }
-  const TileCfg t = kTiles[cfg];
-  a.tiles_m = cdiv(p->M, t.bm);
-  a.tiles_n = cdiv(p->N, t.bn);
   const int64_t nblk = (int64_t)a.tiles_m * a.tiles_n * (split > 1 ? split : p->batch);
   LDM_CHECK_ARG(nblk < (1ll << 31), "ldm_gemm: grid too large");
   dim3 grid((unsigned)nblk);
@@ -456,14 +525,8 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   else launch_mode<float>(cfg, a, grid, s);
   int st = ldm_launch_status("ldm_gemm");
   if (st != LDM_OK) return st;
-  if (split > 1) {
-    const bool vec = a.vec_epilogue && al(p->workspace, 16) && p->N % 4 == 0;
-    int64_t total = vec ? (int64_t)p->M * (nout / 8) : (int64_t)p->M * nout;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    if (vec) hipLaunchKernelGGL(splitk_epilogue_vec_kernel, dim3(blocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, a);
-    st = ldm_launch_status("ldm_gemm(splitk epilogue)");
-  }
+  // defer_reduce: the f32 slabs stay in the workspace; the caller completes the product with
+  // ldm_gemm_reduce or fuses the reduction into the GroupNorm that follows (ldm_groupnorm_splitk)
+  if (split > 1 && !p->defer_reduce) st = launch_reduce(p, a, s);
   return st;
 }

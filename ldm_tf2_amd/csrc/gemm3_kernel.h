@@ -86,9 +86,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   constexpr int ES = 2;
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int NSTAGE = 3;
-  static_assert(NSTAGE * STAGE <= 160 * 1024, "LDS");
+  // LayerNorm fold: 4 KB behind the ring for the row-statistics exchange between the two waves (wn = 0 / 1)
+  // that share 64 rows (ONE __shared__ array: a second object makes the compiler drain vmcnt per step)
+  constexpr int LNX = (EPI & 64) ? NW * 64 * 8 : 0;
+  static_assert(NSTAGE * STAGE + LNX <= 160 * 1024, "LDS");
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE + LNX];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -294,13 +297,32 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
         const u32x4 c1 = *(const u32x4*)(base + (((j + 1 + rot) & 7) << 4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const bf2 a0 = __builtin_bit_cast(bf2, c0[e]), a1 = __builtin_bit_cast(bf2, c1[e]);
+          // (copies first: __builtin_bit_cast applied to the vector ELEMENT expression c0[e] reads element 0
+          // for every e with this compiler -- found by a one-hot probe of which elements the statistics see)
+          const uint32_t w0 = c0[e], w1 = c1[e];
+          const bf2 a0 = __builtin_bit_cast(bf2, w0), a1 = __builtin_bit_cast(bf2, w1);
           ln_s = __builtin_amdgcn_fdot2_f32_bf16(a0, one, ln_s, false);
           ln_q = __builtin_amdgcn_fdot2_f32_bf16(a0, a0, ln_q, false);
           ln_s = __builtin_amdgcn_fdot2_f32_bf16(a1, one, ln_s, false);
           ln_q = __builtin_amdgcn_fdot2_f32_bf16(a1, a1, ln_q, false);
         }
       }
+    }
+  };
+
+  // The two waves that share 64 rows (wn = 0 / 1) split the K-tiles between them (even / odd) and
+  // exchange their partial sums through LDS once, when the first n-tile is complete.
+  [[maybe_unused]] auto ln_publish = [&]() {
+    if constexpr ((EPI & kEpiLn) != 0) {
+      ldm_f32x2 v = {ln_s, ln_q};
+      *(ldm_f32x2*)(smem + NSTAGE * STAGE + (wave * 64 + lane) * 8) = v;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // visible to the partner after the next barrier
+    }
+  };
+  [[maybe_unused]] auto ln_combine = [&]() {
+    if constexpr ((EPI & kEpiLn) != 0) {
+      const ldm_f32x2 o = *(const ldm_f32x2*)(smem + NSTAGE * STAGE + ((wave ^ 1) * 64 + lane) * 8);
+      ln_s += o[0]; ln_q += o[1];
     }
   };
 
@@ -525,11 +547,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     for (int s = 0; s < S; ++s) {
       wait_step(s);
       __builtin_amdgcn_s_barrier();
+      if constexpr (LN) { if (s == nk) ln_combine(); }
       if (ck == 0 && s > 0) { epilogue(ctl - 1); zero_acc(); }
       int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
       if (s + 2 < S) issue_next(sn);
       read_frags(smem + st * STAGE);
-      if constexpr (LN) { if (ctl == 0) ln_accum(smem + st * STAGE); }
+      if constexpr (LN) {
+        if (ctl == 0) {
+          if ((ck & 1) == wn) ln_accum(smem + st * STAGE);
+          if (ck == nk - 1) ln_publish();
+        }
+      }
       multiply(0);
       st = st + 1 == NSTAGE ? 0 : st + 1;
       if (++ck == nk) { ck = 0; ++ctl; }
@@ -539,17 +567,29 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       wait_step(s);
       __builtin_amdgcn_s_barrier();
       if (s > 0) multiply(1);                        // step s - 1, fragments kept in registers
+      if constexpr (LN) { if (s == nk) ln_combine(); }
       if (ck == 0 && s > 0) { epilogue(ctl - 1); zero_acc(); }
       int sn = st + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
       if (s + 2 < S) issue_next(sn);
       read_frags(smem + st * STAGE);
-      if constexpr (LN) { if (ctl == 0) ln_accum(smem + st * STAGE); }
+      if constexpr (LN) {
+        if (ctl == 0) {
+          if ((ck & 1) == wn) ln_accum(smem + st * STAGE);
+          if (ck == nk - 1) ln_publish();
+        }
+      }
       st = st + 1 == NSTAGE ? 0 : st + 1;
       if (++ck == nk) { ck = 0; ++ctl; }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
     multiply(1);
+  }
+  if constexpr (LN) {
+    if (ntl == 1) {                                  // one n-tile: no barrier period followed the exchange yet
+      __builtin_amdgcn_s_barrier();
+      ln_combine();
+    }
   }
   epilogue(ntl - 1);
 #endif
@@ -558,5 +598,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
 // returns false when the (tile, epilogue) combination is not instantiated
 template <int MODE>
 bool launch_gemm3(int tn, int epi, const Gemm3Args& a, dim3 grid, hipStream_t s);
+// the LayerNorm-fold variants (EPI bit 6, plain rows), gemm3_inst_ln.hip
+bool launch_gemm3_ln(int tn, int epi, const Gemm3Args& a, dim3 grid, hipStream_t s);
 
 }  // namespace ldm_gemm_detail

@@ -302,211 +302,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
-// ---- single-launch GroupNorm (+SiLU) for the U-Net's image sizes ---------------------------
-// One workgroup owns GB whole groups of one sample: its [HW][GB*cpg] slab (S 16-byte chunks
-// per pixel) is read from HBM ONCE, kept in registers between the passes (mean; centred
-// sum of squares; normalise) and written once.  No partial buffer, no second launch, and the
-// variance is the two-pass form.  Thread t owns chunk column cs = t % S of pixels t/S,
-// t/S + P, ...; a 16-byte chunk spans at most two groups (cpg >= elements per chunk), so a
-// thread carries two running sums.  Reductions are fixed-order (no float atomics): results
-// do not depend on scheduling.  Blocks of one sample share i % 8, i.e. one XCD's L2, which
-// also holds the other halves of the partially used cache lines.
-struct GnFusedPlan { int GB, S, NT, maxch; };
-
-// keeps the compiler from hoisting the three passes' conversions of the register-resident
-// slab into one (which would hold every element as a float at once)
-__device__ __forceinline__ u32x4 opaque(u32x4 c) {
-  asm volatile("" : "+v"(c));
-  return c;
-}
-
-inline bool gn_fused_plan(int B, int HW, int C, int G, int esize, GnFusedPlan* pl) {
-  if (G <= 0 || C % G) return false;
-  const int epc = 16 / esize, cpg = C / G;
-  if (cpg < epc) return false;
-  int GB = 0;
-  for (int g = 1; g <= 8; g *= 2)
-    if (G % g == 0 && (g * cpg) % epc == 0) { GB = g; break; }
-  if (!GB) return false;
-  const int S = GB * cpg / epc;
-  if (S > 64) return false;
-  // small slabs: ONE wave per workgroup (block barriers degenerate, reductions are pure
-  // butterflies), up to 24 chunks per lane
-  // (measured: pays when the launch still has >= 2 waves per CU at <= 16 chunks per lane, or
-  // >= 4 per CU at <= 24)
-  {
-    const int need = (HW + 64 / S - 1) / (64 / S);
-    const int64_t waves = (int64_t)B * (G / GB);
-    if (need <= 8 && waves >= 512) { *pl = {GB, S, 64, 8}; return true; }
-    if (need <= 16 && waves >= 512) { *pl = {GB, S, 64, 16}; return true; }
-    if (need <= 24 && waves >= 1024) { *pl = {GB, S, 64, 24}; return true; }
-  }
-  // few chunks per thread (register budget: 4 VGPRs each), more threads before more chunks
-  for (int NT : {256, 512, 1024}) {
-    const int need = (HW + NT / S - 1) / (NT / S);
-    if (need <= 8) { *pl = {GB, S, NT, 8}; return true; }
-    if (need <= 16) { *pl = {GB, S, NT, 16}; return true; }
-  }
-  for (int NT : {256, 512}) {
-    const int need = (HW + NT / S - 1) / (NT / S);
-    if (need <= 24) { *pl = {GB, S, NT, 24}; return true; }
-  }
-  return false;
-}
-
-template <typename T, int NT, int MAXCH>
-__global__ __launch_bounds__(NT, ((MAXCH <= 8 || (MAXCH <= 16 && NT > 64)) ? 4 : 2)) void gn_fused_kernel(const T* __restrict__ x, int64_t ldx,
-                                                      const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta,
-                                                      T* __restrict__ out, int64_t ldo, int B, int HW,
-                                                      int C, int G, int GB, int S, float eps,
-                                                      int do_silu) {
-  constexpr int EPC = Elem<T>::kPerChunk;
-  constexpr int NW = NT / 64;
-  __shared__ float s_part[NT == 64 ? 1 : NT][2];
-  __shared__ float s_tot[64][2];
-  __shared__ float s_red[8], s_mean[8], s_rstd[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nblk = G / GB;
-  const int bi = blockIdx.x;
-  const int b = (bi & 7) + 8 * ((bi >> 3) / nblk), blk = (bi >> 3) % nblk;
-  if (b >= B) return;                               // uniform per block
-  const int cpg = C / G;
-  const int P = NT / S;
-  const int pl = tid / S, cs = tid - pl * S;
-  const bool active = pl < P;
-  const int e0 = cs * EPC;                          // first element of my chunk in the segment
-  const int g_lo = e0 / cpg;
-  const int nlo = min(EPC, (g_lo + 1) * cpg - e0);  // my chunk's elements that belong to g_lo
-  const int c0 = blk * GB * cpg + e0;               // first channel of my chunk
-  const T* xb = x + (int64_t)b * HW * ldx + c0;
-
-  u32x4 v[MAXCH];
-#pragma unroll
-  for (int k = 0; k < MAXCH; ++k) {
-    const int p = pl + k * P;
-    u32x4 z = {0u, 0u, 0u, 0u};
-    v[k] = z;
-    if (active && p < HW) v[k] = *(const u32x4*)(xb + (int64_t)p * ldx);
-  }
-  float gm[EPC], bt[EPC];                           // fetched now: off the post-reduction critical path
-#pragma unroll
-  for (int e = 0; e < EPC; ++e) {
-    gm[e] = active ? gamma[c0 + e] : 0.f;
-    bt[e] = active ? beta[c0 + e] : 0.f;
-  }
-
-  // fixed-order block reduction of a (lo, hi) pair per thread -> s_red[g], g < GB
-  // (a lane's lo belongs to group g_lo, its hi to g_lo + 1): per group one wave butterfly over
-  // the lanes' selected contributions, then the waves' partials are added in wave order
-  auto reduce_groups = [&](float lo, float hi) {
-    if constexpr (NT == 64) {
-      for (int g = 0; g < GB; ++g) {
-        const float mine = (g == g_lo ? lo : 0.f) + (g == g_lo + 1 ? hi : 0.f);
-        const float t = wave_sum(mine);
-        if (lane == 0) s_red[g] = t;
-      }
-      __syncthreads();
-    } else {
-      // multi-wave workgroups: per chunk column (fixed lo/hi split) over the pixel lanes, then
-      // the columns of each group
-      s_part[tid][0] = lo; s_part[tid][1] = hi;
-      __syncthreads();
-      for (int c = wave; c < S; c += NW) {
-        float a0 = 0.f, a1 = 0.f;
-        for (int q = lane; q < P; q += 64) { a0 += s_part[q * S + c][0]; a1 += s_part[q * S + c][1]; }
-        a0 = wave_sum(a0); a1 = wave_sum(a1);
-        if (lane == 0) { s_tot[c][0] = a0; s_tot[c][1] = a1; }
-      }
-      __syncthreads();
-      if (tid < GB) {
-        float t = 0.f;
-        for (int c = 0; c < S; ++c) {
-          const int ec = c * EPC, gl = ec / cpg;
-          const int nl = min(EPC, (gl + 1) * cpg - ec);
-          if (gl == tid) t += s_tot[c][0];
-          if (nl < EPC && gl + 1 == tid) t += s_tot[c][1];
-        }
-        s_red[tid] = t;
-      }
-      __syncthreads();
-    }
-  };
-
-  const float n = (float)HW * (float)cpg;
-  {
-    float lo = 0.f, hi = 0.f;                       // padding chunks are zeros: no predicate needed
-#pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      float f[EPC];
-      chunk_to_f32(opaque(v[k]), f, T());
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) { if (e < nlo) lo += f[e]; else hi += f[e]; }
-    }
-    reduce_groups(lo, hi);
-    if (tid < GB) s_mean[tid] = s_red[tid] / n;
-    __syncthreads();
-  }
-  const float m_lo = s_mean[g_lo], m_hi = s_mean[min(g_lo + 1, GB - 1)];
-  {
-    float lo = 0.f, hi = 0.f;
-#pragma unroll
-    for (int k = 0; k < MAXCH; ++k) {
-      if (!(active && pl + k * P < HW)) continue;
-      float f[EPC];
-      chunk_to_f32(opaque(v[k]), f, T());
-#pragma unroll
-      for (int e = 0; e < EPC; ++e) {
-        const float d = f[e] - (e < nlo ? m_lo : m_hi);
-        if (e < nlo) lo += d * d; else hi += d * d;
-      }
-    }
-    reduce_groups(lo, hi);
-    if (tid < GB) s_rstd[tid] = rsqrtf(s_red[tid] / n + eps);
-    __syncthreads();
-  }
-  if (!active) return;
-  float mu[EPC], sc[EPC], sh[EPC];
-  {
-    const float r_lo = s_rstd[g_lo], r_hi = s_rstd[min(g_lo + 1, GB - 1)];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      mu[e] = e < nlo ? m_lo : m_hi;
-      sc[e] = (e < nlo ? r_lo : r_hi) * gm[e];
-      sh[e] = bt[e];
-    }
-  }
-  T* ob = out + (int64_t)b * HW * ldo + c0;
-#pragma unroll
-  for (int k = 0; k < MAXCH; ++k) {
-    const int p = pl + k * P;
-    if (p >= HW) continue;
-    float f[EPC];
-    chunk_to_f32(opaque(v[k]), f, T());
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) {
-      const float y = (f[e] - mu[e]) * sc[e] + sh[e];
-      f[e] = do_silu ? silu_f(y) : y;
-    }
-    *(u32x4*)(ob + (int64_t)p * ldo) = f32_to_chunk(f, T());
-  }
-}
-
-template <typename T>
-void gn_fused_launch(const GnFusedPlan& pl, dim3 grid, hipStream_t s, const void* x, int64_t ldx,
-                     const float* gamma, const float* beta, void* out, int64_t ldo, int B, int HW, int C,
-                     int G, float eps, int silu) {
-#define GNF(NT_, MC_)                                                                                  \
-  hipLaunchKernelGGL((gn_fused_kernel<T, NT_, MC_>), grid, dim3(NT_), 0, s, (const T*)x, ldx, gamma,   \
-                     beta, (T*)out, ldo, B, HW, C, G, pl.GB, pl.S, eps, silu)
-  if (pl.NT == 64) { if (pl.maxch == 8) GNF(64, 8); else if (pl.maxch == 16) GNF(64, 16); else GNF(64, 24); }
-  else if (pl.NT == 256) { if (pl.maxch == 8) GNF(256, 8); else if (pl.maxch == 16) GNF(256, 16); else GNF(256, 24); }
-  else if (pl.NT == 512) { if (pl.maxch == 8) GNF(512, 8); else if (pl.maxch == 16) GNF(512, 16); else GNF(512, 24); }
-  else { if (pl.maxch == 8) GNF(1024, 8); else GNF(1024, 16); }
-#undef GNF
-}
-
 }  // namespace
+
+#include "gn_fused.h"
+using namespace ldm_gn;
 
 extern "C" int ldm_groupnorm_fused_supported(int B, int HW, int C, int groups, int dtype) {
   if (!(dtype == LDM_F32 || dtype == LDM_BF16) || B <= 0 || HW <= 0 || C <= 0) return 0;

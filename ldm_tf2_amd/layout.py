@@ -72,6 +72,24 @@ def geglu_kernel(k_io, bias, dtype, device):
   return _dev(inter, dtype, device), _dev(bi, torch.float32, device)
 
 
+def ln_fold(wt_nk, gamma, beta, bias, dtype, device):
+  """LayerNorm -> Dense folded for ldm_gemm's `ln_cs` form (include/ldm_hip.h): from the device-layout
+  float32 matrix wt [N, K] (rows = outputs), the LayerNorm's gamma / beta [K] and the Dense bias [N]
+  (or None) returns (w', cs, b') on the device with
+      w' = dtype(gamma (.) W),  cs[n] = sum_k float(w'[n, k]),  b' = bias + W beta   (float32),
+  so that LN(x) W^T + bias = rstd (x w'^T - mean cs) + b'.  cs is summed from the ROUNDED w' (what
+  the MFMA multiplies), in float64, so that the mean term cancels exactly what the product carries."""
+  w = wt_nk.detach().to("cpu", torch.float32)
+  g = torch.as_tensor(np.asarray(gamma), dtype=torch.float32)
+  b = torch.as_tensor(np.asarray(beta), dtype=torch.float32)
+  wq = (w * g[None, :]).to(dtype)
+  cs = wq.to(torch.float64).sum(1).to(torch.float32)
+  bb = (w.to(torch.float64) @ b.to(torch.float64)).to(torch.float32)
+  if bias is not None:
+    bb = bb + torch.as_tensor(np.asarray(bias), dtype=torch.float32)
+  return wq.contiguous().to(device), cs.contiguous().to(device), bb.contiguous().to(device)
+
+
 def vec(a, device):
   return _dev(a, torch.float32, device)
 

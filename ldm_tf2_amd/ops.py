@@ -24,6 +24,7 @@ __all__ = [
 ]
 
 _TORCH_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_byref = C.byref      # (functions below use C for a channel count)
 _WS = {}
 _WS_BYTES = 96 << 20
 
@@ -168,6 +169,8 @@ def plan_key(p) -> str:
       p.M, p.N, p.K, p.batch, p.conv, p.H, p.W, p.stride, p.upsample, p.no_lead_pad, p.act, p.dtype, p.out_dtype)
   if p.out2 and p.n_split == 0:
     key += " t1"            # whole product stored transposed (linear_t)
+  if p.ln_cs:
+    key += " ln1"           # LayerNorm of the rows folded in (persistent tiles only)
   return key
 
 
@@ -310,16 +313,75 @@ def resolve_plan(p: GemmParams):
     if _PLAN_RECORD is not None:
       _PLAN_RECORD[key] = (p.M, p.N, p.K, p.batch, p.act, p.dtype)
     plan = active.get(key)
+    if plan is None and p.ln_cs:
+      # a LayerNorm-fold launch without an entry of its own inherits the plain product's plan when
+      # that names a persistent tile (13 = 160-column, 14 = 128-column n-tiles)
+      plan = active.get(key[:-len(" ln1")])
+      if plan is not None and plan[0] not in _PERSISTENT_TILES:
+        plan = None
     if plan is not None:
       p.tile, p.split_k = plan
       return True
   return False
 
 
+class PendingReduce:
+  """A split-K product whose float32 slabs wait in the workspace (ldm_gemm with defer_reduce): complete it
+  with `finish` (plain reduce) or `groupnorm(..., pending=...)` (reduce + GroupNorm in one launch) before
+  anything else uses that workspace or reads `out`."""
+
+  def __init__(self, p, out, ws, keep):
+    self.p, self.out, self.ws, self.keep, self.done = p, out, ws, keep, False
+
+
+def _outstanding():
+  st = getattr(_TLS, "pending", None)
+  if st is None:
+    st = _TLS.pending = {}
+  return st
+
+
+def finish(pending):
+  """Completes a deferred split-K product with the plain reduce + epilogue launch."""
+  if pending is None or pending.done:
+    return
+  check(lib.ldm_gemm_reduce(C.byref(pending.p), _stream()), "ldm_gemm_reduce")
+  pending.done = True
+  _outstanding().pop(pending.ws.data_ptr(), None)
+
+
+def _gemm_deferred(p: GemmParams, device, out, keep):
+  """ldm_gemm with the reduce left to the caller.  Returns a PendingReduce, or None when the plan does
+  not split K (the product is then complete)."""
+  ws = workspace(device)
+  if ws.data_ptr() in _outstanding():
+    raise RuntimeError("ldm_gemm: this workspace still holds the slabs of a deferred split-K product")
+  p.workspace = ws.data_ptr()
+  p.workspace_bytes = ws.numel()
+  planned = resolve_plan(p)
+  if lib.ldm_gemm_splits(C.byref(p)) <= 1:
+    st = lib.ldm_gemm(C.byref(p), _stream())
+    if st == _lib.ERR_ARG and planned:
+      p.tile, p.split_k = 0, 0
+      if lib.ldm_gemm_splits(C.byref(p)) > 1:
+        return _gemm_deferred(p, device, out, keep)
+      st = lib.ldm_gemm(C.byref(p), _stream())
+    check(st, "ldm_gemm")
+    return None
+  p.defer_reduce = 1
+  check(lib.ldm_gemm(C.byref(p), _stream()), "ldm_gemm")
+  pend = PendingReduce(p, out, ws, keep)
+  _outstanding()[ws.data_ptr()] = pend
+  return pend
+
+
 def _gemm(p: GemmParams, device):
   """Every ldm_gemm launch of the package goes through here (tools/gemm_hooks.py wraps this
   one function for measurements; the product path itself carries no hooks)."""
   ws = workspace(device)
+  if ws.data_ptr() in _outstanding():
+    raise RuntimeError("ldm_gemm: this workspace still holds the slabs of a deferred split-K product "
+                       "(ops.finish it, or let the GroupNorm that follows consume it, first)")
   p.workspace = ws.data_ptr()
   p.workspace_bytes = ws.numel()
   planned = resolve_plan(p)
@@ -340,13 +402,16 @@ def linear_ln_supported(n_out, dtype):
 
 
 def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_rows=0,
-           alpha=1.0, tile=0, split_k=0, ln=None, out2=None):
+           alpha=1.0, tile=0, split_k=0, ln=None, out2=None, ln_fold=None):
   """out[..., n] = act(alpha * x[..., :] . wt[n, :] + bias[n] + addend[group]) + residual.
   x [..., K]; wt [N, K] contiguous; out [..., N] (N/2 wide for GEGLU).
   `ln=(gamma, beta, ln_out, eps)`: also writes ln_out = LayerNorm(out) (same shape/dtype).
   `out2` [G, N2, T']: the weight rows beyond out's width are a second projection whose result is
   stored TRANSPOSED per group of T = M/G rows (q|k into `out`, v into the attention kernel's
-  V^T [rows, heads*Sp, T] in one launch)."""
+  V^T [rows, heads*Sp, T] in one launch).
+  `ln_fold=(cs, eps)`: out = LayerNorm(x) . W^T + b with the normalisation folded into the product:
+  `wt` holds gamma (.) W, `bias` holds b + W beta, cs[n] = sum_k wt[n, k] (layout.ln_fold); the kernel
+  derives the row statistics itself (bf16, persistent tiles)."""
   K = x.shape[-1]
   N = wt.shape[0]
   M = x.numel() // K
@@ -376,6 +441,10 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
     assert ln_out.dtype == out.dtype and tuple(ln_out.shape) == tuple(out.shape)
     p.ln_out, p.ld_ln, p.ln_eps = _ptr(ln_out), row_ld(ln_out), float(eps)
     p.ln_gamma, p.ln_beta = _ptr(_f32(gamma, "ln gamma")), _ptr(_f32(beta, "ln beta"))
+  if ln_fold is not None:
+    cs, eps = ln_fold
+    assert bias is not None and tuple(cs.shape) == (N,) and cs.is_contiguous()
+    p.ln_cs, p.ln_eps = _ptr(_f32(cs, "ln_fold column sums")), float(eps)
   _gemm(p, x.device)
   return out
 
@@ -391,7 +460,7 @@ def linear_t_supported(x, wt, out_t):
           out_t.stride(1) % 8 == 0 and out_t.stride(0) % 8 == 0)
 
 
-def linear_t(x, wt, out_t, tile=0):
+def linear_t(x, wt, out_t, tile=0, bias=None, ln_fold=None):
   """out_t[g, n, t] = sum_k x[g * T + t, k] * wt[n, k] with T = M / G: the product stored
   TRANSPOSED per group of T rows (the self-attention V projection lands directly in the attention
   kernel's V^T [rows, heads*Sp, T]).  Runs on the persistent kernel (tile 13 / 14; the plan table
@@ -410,6 +479,11 @@ def linear_t(x, wt, out_t, tile=0):
   p.act, p.dtype, p.out_dtype, p.alpha = ACT_NONE, code(x.dtype), code(out_t.dtype), 1.0
   p.n_split, p.rows2, p.ld2, p.stride2 = 0, M // G, out_t.stride(1), out_t.stride(0)
   p.tile = tile
+  if ln_fold is not None:                # LayerNorm of the rows folded in (see linear)
+    cs, eps = ln_fold
+    assert bias is not None and tuple(cs.shape) == (N,) and cs.is_contiguous()
+    p.bias = _ptr(_f32(bias, "bias"))
+    p.ln_cs, p.ln_eps = _ptr(_f32(cs, "ln_fold column sums")), float(eps)
   resolve_plan(p)
   if p.tile not in _PERSISTENT_TILES:
     p.tile, p.split_k = (14 if N % 128 == 0 else 13), 0
@@ -452,7 +526,7 @@ def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, spl
 
 
 def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residual=None,
-            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False, no_lead_pad=False):
+            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False, no_lead_pad=False, defer_reduce=False):
   """3x3 convolution, NHWC, pad 1 (Keras SAME for stride 1; the U-Net's explicit
   pad(1,1)+VALID for stride 2; `no_lead_pad`: the autoencoder's pad (0,1),(0,1)+VALID stride-2
   downsample, autoencoder.py:133), optional fused nearest-2x upsample of the input and optional
@@ -460,6 +534,9 @@ def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residu
   x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout]."""
   p = _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale,
                    a_shift, a_silu, no_lead_pad)
+  if defer_reduce and a_scale is None:
+    # -> PendingReduce when the plan splits K (the caller owes `finish` or a consuming groupnorm), else None
+    return _gemm_deferred(p, x.device, out, (x, wt, bias, addend, residual))
   _gemm(p, x.device)
   return out
 
@@ -506,12 +583,28 @@ def conv3x3_small(x, kernel_hwio, bias, out):
   return out
 
 
-def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None, fused=None):
+def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None, fused=None, pending=None,
+              store_x=True):
   """x, out [B, H, W, C] (channel slices allowed).  Small images take the single-launch
   kernel (`fused`; default: whenever the library supports the shape), large ones the
-  partial-sums + apply pair."""
+  partial-sums + apply pair.
+  `pending`: x is the output of a deferred split-K product (conv3x3(..., defer_reduce=True)): its reduce +
+  epilogue and this GroupNorm run as ONE launch (ldm_groupnorm_splitk); x itself is written only when
+  `store_x` (a ResBlock's conv1 output has no other reader)."""
   B, C = x.shape[0], x.shape[-1]
   HW = x.numel() // (B * C)
+  if pending is not None and not pending.done:
+    same = (pending.out.data_ptr() == x.data_ptr() and tuple(pending.out.shape) == tuple(x.shape) and
+            pending.out.stride() == x.stride())
+    if same and lib.ldm_groupnorm_splitk_supported(B, HW, C, groups, code(x.dtype)) and row_ld(x) == pending.p.ldc_m:
+      assert out.dtype == x.dtype
+      check(lib.ldm_groupnorm_splitk(_byref(pending.p), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
+                                     _ptr(out), row_ld(out), B, HW, groups, float(eps), int(bool(silu)),
+                                     int(bool(store_x)), _stream()), "ldm_groupnorm_splitk")
+      pending.done = True
+      _outstanding().pop(pending.ws.data_ptr(), None)
+      return out
+    finish(pending)
   if fused is None:
     fused = True
   if fused and lib.ldm_groupnorm_fused_supported(B, HW, C, groups, code(x.dtype)):

@@ -53,7 +53,7 @@ class _Res:
 class _ST:
   """SpatialTransformer weights (unet.py:341-354, :295-306, :248-265, :317-338)."""
 
-  def __init__(self, w, p, heads, dtype, dev):
+  def __init__(self, w, p, heads, dtype, dev, fold_ln=False):
     g = lambda n: w[p + "/" + n]
     c = g("dense1/kernel").shape[0]
     self.c, self.heads = c, heads
@@ -77,6 +77,19 @@ class _ST:
     self.ff_out = (L.dense_kernel(g("block/ffn/dense/kernel"), dtype, dev), L.vec(g("block/ffn/dense/bias"), dev))
     self.ln = [(L.vec(g(f"block/layernorm{i}/gamma"), dev), L.vec(g(f"block/layernorm{i}/beta"), dev))
                for i in (1, 2, 3)]
+    # bf16: the three LayerNorms folded into the projections they feed (ldm_gemm ln_cs): (w', cs, b')
+    self.fold = None
+    if fold_ln:
+      lnp = [(g(f"block/layernorm{i}/gamma"), g(f"block/layernorm{i}/beta")) for i in (1, 2, 3)]
+      f32, cpu = torch.float32, "cpu"
+      qk_f = torch.cat([L.split_kernel(w[a1 + "/query/kernel"], sp, f32, cpu),
+                        L.split_kernel(w[a1 + "/key/kernel"], sp, f32, cpu)], 0)
+      gw, gb = L.geglu_kernel(g("block/ffn/geglu/kernel"), g("block/ffn/geglu/bias"), f32, cpu)
+      self.fold = dict(
+          qk1=L.ln_fold(qk_f, lnp[0][0], lnp[0][1], None, dtype, dev),
+          v1=L.ln_fold(L.split_kernel(w[a1 + "/value/kernel"], sp, f32, cpu), lnp[0][0], lnp[0][1], None, dtype, dev),
+          q2=L.ln_fold(L.split_kernel(w[a2 + "/query/kernel"], sp, f32, cpu), lnp[1][0], lnp[1][1], None, dtype, dev),
+          geglu=L.ln_fold(gw, lnp[2][0], lnp[2][1], gb.numpy(), dtype, dev))
     self.ctx_k = self.ctx_vt = None     # filled by UNet.set_context
 
 
@@ -90,7 +103,8 @@ class UNet:
                attention_resolutions=(4, 2, 1), dropout_rate=0.1, channel_mult=(1, 2, 4, 4),
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
-               split_qkv=True, small_conv_out=False):
+               split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
+               defer_reduce=True):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -108,6 +122,15 @@ class UNet:
     # bf16: q|k and v as two persistent-kernel launches (v stored transposed); split_qkv=False: A/B
     self._split_qkv = dtype == torch.bfloat16 and bool(split_qkv)
     self._small_conv_out = bool(small_conv_out)
+    # bf16: each LayerNorm of the transformer blocks (unet.py:309-313) is folded into the projection it
+    # feeds -- LN(x) W^T = rstd (x (gamma (.) W)^T - mean colsum) + W beta -- and the persistent GEMM derives
+    # the row statistics from the A tiles it stages anyway: 48 LayerNorm launches and their normalised
+    # copies of the residual stream disappear.  Only where the launch has enough rows to fill the chip
+    # on the persistent kernel (fold_min_rows); float32 keeps the separate LayerNorm (parity mode).
+    self._fold_ln = dtype == torch.bfloat16 and bool(fold_layernorm) and not self._fuse_ln
+    self._fold_min_rows = int(fold_min_rows)
+    self._defer_reduce = bool(defer_reduce)   # split-K reduces fused into the consuming GroupNorm (A/B: False)
+    self._pend = None
     self._fuse_cache = {}
     self._model_channels = model_channels
     self._out_channels = out_channels
@@ -143,7 +166,7 @@ class UNet:
       return r
 
     def mk_st(p):
-      return _ST(w, p, H, dt, dev) if (p + "/dense1/kernel") in w else None
+      return _ST(w, p, H, dt, dev, fold_ln=self._fold_ln) if (p + "/dense1/kernel") in w else None
 
     self.in_blocks, self.skip_ch, self.skip_lvl = [], [mc], [0]
     lvl, i = 0, 0
@@ -239,19 +262,57 @@ class UNet:
       return ops.conv3x3(x, conv[0], out, bias=conv[1], a_scale=sc, a_shift=sh, a_silu=True,
                          tile=0 if fused is True else fused, **kw)
     t0 = B_.get("gn", tuple(x.shape), dt)
-    ops.groupnorm(x, gn[0], gn[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
+    self._gn(x, gn, GN_EPS_RES, True, t0)
     return ops.conv3x3(t0, conv[0], out, bias=conv[1], **kw)
+
+  # ---- split-K products whose reduce is fused into the GroupNorm that consumes them ---------------
+  # A split-K convolution leaves float32 slabs; its reduce + epilogue launch is followed, almost
+  # everywhere in the U-Net, by the GroupNorm of exactly that tensor.  `_conv_deferred` launches only the
+  # main kernel and parks the slabs (self._pend); `_gn` completes them inside the GroupNorm launch
+  # (ldm_groupnorm_splitk: same value, bit for bit, one launch and one bf16 round trip less).  Whatever
+  # else is about to read the tensor or use the workspace calls `_flush` first (plain reduce).
+  def _flush(self):
+    if self._pend is not None:
+      ops.finish(self._pend)
+      self._pend = None
+
+  def _conv_deferred(self, x, wt, out, **kw):
+    self._flush()
+    r = ops.conv3x3(x, wt, out, defer_reduce=self._defer_reduce, **kw)
+    self._pend = r if isinstance(r, ops.PendingReduce) else None
+    return out
+
+  def _gn(self, x, gn, eps, silu, out, store_x=True):
+    pend, self._pend = self._pend, None
+    ops.groupnorm(x, gn[0], gn[1], out, eps, silu=silu, partial=self._gnp, pending=pend, store_x=store_x)
+    return out
 
   def _res(self, r, x, tall, out):
     B_, dt = self.buf, self.dtype
     R, h, w, _ = x.shape
-    h1 = B_.get("h1", (R, h, w, r.cout), dt)
-    self._gn_conv(x, r.gn1, r.conv1, h1, addend=tall[:, r.temb_off:r.temb_off + r.cout])
+    if self.fuse_groupnorm:               # halo-conv prologue path (opt-in): no deferred reduces
+      self._flush()
+      h1 = B_.get("h1", (R, h, w, r.cout), dt)
+      self._gn_conv(x, r.gn1, r.conv1, h1, addend=tall[:, r.temb_off:r.temb_off + r.cout])
+      res = x
+      if r.shortcut is not None:
+        res = B_.get("sc", (R, h, w, r.cout), dt)
+        ops.linear(x, r.shortcut[0], res, bias=r.shortcut[1])
+      self._gn_conv(h1, r.gn2, r.conv2, out, residual=res)
+      return out
+    # GN1 first: it completes a deferred product that produced x (x is materialised by that launch)
+    t0 = B_.get("gn", tuple(x.shape), dt)
+    self._gn(x, r.gn1, GN_EPS_RES, True, t0)
     res = x
-    if r.shortcut is not None:
+    if r.shortcut is not None:            # before conv1: the slabs of conv1 must survive until GN2
       res = B_.get("sc", (R, h, w, r.cout), dt)
       ops.linear(x, r.shortcut[0], res, bias=r.shortcut[1])
-    self._gn_conv(h1, r.gn2, r.conv2, out, residual=res)
+    h1 = B_.get("h1", (R, h, w, r.cout), dt)
+    self._conv_deferred(t0, r.conv1[0], h1, bias=r.conv1[1], addend=tall[:, r.temb_off:r.temb_off + r.cout])
+    t1 = B_.get("gn", (R, h, w, r.cout), dt)
+    self._gn(h1, r.gn2, GN_EPS_RES, True, t1, store_x=False)      # h1 has no other reader (unet.py:388-390)
+    # conv2's reduce is left to the next GroupNorm (the following block's first op) when that reads `out`
+    self._conv_deferred(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
     return out
 
   def _st(self, st, x, out):
@@ -260,7 +321,7 @@ class UNet:
     T, hs = h * w, st.heads * st.sp
     scale = st.s ** -0.5
     t0 = B_.get("gn", (R, h, w, c), dt)
-    ops.groupnorm(x, st.gn[0], st.gn[1], t0, GN_EPS_ST, silu=False, partial=self._gnp)
+    self._gn(x, st.gn, GN_EPS_ST, False, t0)
     ha = B_.get("st_a", (R, T, c), dt)
     ln = B_.get("st_ln", (R, T, c), dt)
     # each LayerNorm of the block normalises a row the preceding projection has just produced:
@@ -268,13 +329,20 @@ class UNet:
     fuse_ln = self._fuse_ln and ops.linear_ln_supported(c, dt)
     lnp = lambda i: (st.ln[i][0], st.ln[i][1], ln, LN_EPS) if fuse_ln else None
     ops.linear(t0, st.proj_in[0], ha, bias=st.proj_in[1], ln=lnp(0))
-    # self-attention (unet.py:309-310)
-    if not fuse_ln:
-      ops.layernorm(ha, st.ln[0][0], st.ln[0][1], ln, LN_EPS)
     qk = B_.get("st_qk", (R, T, 2 * hs), dt)
     tp = (T + 7) // 8 * 8
     vt = B_.get("st_vt", (R, hs, tp), dt, zero=True)
-    if self._split_qkv and ops.linear_t_supported(ln, st.v1, vt):
+    # LayerNorm folded into its consumer (bf16, launches with enough rows for the persistent kernel)
+    fold = st.fold if (st.fold is not None and R * T >= self._fold_min_rows and T % 32 == 0) else None
+    # self-attention (unet.py:309-310)
+    if fold is not None:
+      ops.linear(ha, fold["qk1"][0], qk, bias=fold["qk1"][2], ln_fold=(fold["qk1"][1], LN_EPS))
+      ops.linear_t(ha, fold["v1"][0], vt, bias=fold["v1"][2], ln_fold=(fold["v1"][1], LN_EPS))
+    elif not fuse_ln:
+      ops.layernorm(ha, st.ln[0][0], st.ln[0][1], ln, LN_EPS)
+    if fold is not None:
+      pass
+    elif self._split_qkv and ops.linear_t_supported(ln, st.v1, vt):
       # bf16: q|k row-major and v TRANSPOSED (straight into the attention kernel's V^T layout) as two
       # launches that can both take the persistent kernel (ops.linear_t)
       ops.linear(ln, st.qk1, qk)
@@ -290,17 +358,24 @@ class UNet:
     hb = B_.get("st_b", (R, T, c), dt)
     ops.linear(att, st.o1[0], hb, bias=st.o1[1], residual=ha, ln=lnp(1))
     # cross-attention (unet.py:311-312)
-    if not fuse_ln:
-      ops.layernorm(hb, st.ln[1][0], st.ln[1][1], ln, LN_EPS)
     q = B_.get("st_q", (R, T, hs), dt)
-    ops.linear(ln, st.q2, q)
+    if fold is not None:
+      ops.linear(hb, fold["q2"][0], q, bias=fold["q2"][2], ln_fold=(fold["q2"][1], LN_EPS))
+    else:
+      if not fuse_ln:
+        ops.layernorm(hb, st.ln[1][0], st.ln[1][1], ln, LN_EPS)
+      ops.linear(ln, st.q2, q)
     ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale)
     ops.linear(att, st.o2[0], ha, bias=st.o2[1], residual=hb, ln=lnp(2))
     # GEGLU feed-forward (unet.py:313, :323-325, :335-338)
-    if not fuse_ln:
-      ops.layernorm(ha, st.ln[2][0], st.ln[2][1], ln, LN_EPS)
     ff = B_.get("st_ff", (R, T, 4 * c), dt)
-    ops.linear(ln, st.geglu[0], ff, bias=st.geglu[1], act=ops.ACT_GEGLU)
+    if fold is not None:
+      ops.linear(ha, fold["geglu"][0], ff, bias=fold["geglu"][2], act=ops.ACT_GEGLU,
+                 ln_fold=(fold["geglu"][1], LN_EPS))
+    else:
+      if not fuse_ln:
+        ops.layernorm(ha, st.ln[2][0], st.ln[2][1], ln, LN_EPS)
+      ops.linear(ln, st.geglu[0], ff, bias=st.geglu[1], act=ops.ACT_GEGLU)
     ops.linear(ff, st.ff_out[0], hb, bias=st.ff_out[1], residual=ha)
     ops.linear(hb, st.proj_out[0], out, bias=st.proj_out[1], residual=x)
     return out
@@ -312,7 +387,11 @@ class UNet:
     t_rows declares that all rows carry t_rows[0]."""
     # launch plans measured for this step configuration (ops.plan_scope), none otherwise
     with ops.plan_scope(x.shape[0], x.shape[1], self.dtype), ops.workspace_scope(self._ws):
-      return self._forward(x, t_rows, steps, index, out, shared_t)
+      self._pend = None
+      try:
+        return self._forward(x, t_rows, steps, index, out, shared_t)
+      finally:
+        self._flush()
 
   def _forward(self, x, t_rows, steps, index, out, shared_t):
     assert x.dtype == torch.float32 and x.is_contiguous()
@@ -352,7 +431,7 @@ class UNet:
     for i, blk in enumerate(self.in_blocks):
       dst = skip_dst(i + 1)
       if blk[0] == "down":
-        ops.conv3x3(cur, blk[1], dst, bias=blk[2], stride=2)
+        self._conv_deferred(cur, blk[1], dst, bias=blk[2], stride=2)     # (flushes first: it reads cur)
       else:
         _, r, st = blk
         if st is None:
@@ -383,9 +462,10 @@ class UNet:
         stages_left = 1 if up is not None else 0
         o = self._st(st, o, dst if stages_left == 0 else B_.get("blk_s", (R, hh, ww, r.cout), dt))
       if up is not None:
+        self._flush()                                           # it reads o
         ops.conv3x3(o, up[0], dst, bias=up[1], upsample=True)   # unet.py:44-47
     t0 = B_.get("gn", tuple(final.shape), dt)
-    ops.groupnorm(final, self.gn_out[0], self.gn_out[1], t0, GN_EPS_RES, silu=True, partial=self._gnp)
+    self._gn(final, self.gn_out, GN_EPS_RES, True, t0)
     if out is None:
       out = torch.empty(R, h, w, self._out_channels, dtype=f32, device=self.device)
     if self.conv_out_mm is not None:

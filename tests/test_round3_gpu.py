@@ -1,0 +1,213 @@
+"""Round-3 kernels and launch forms against the CPU oracle (through the C ABI).
+
+* LayerNorm folded into the consuming projection (ldm_gemm `ln_cs`, unet.py:309-313): the oracle
+  runs layer_norm -> dense on the same bf16-rounded rows with the UNFOLDED float32 weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from ldm_tf2_amd import layout as L  # noqa: E402
+from ldm_tf2_amd import weights as Wt  # noqa: E402
+from oracle import ldm_oracle as O  # noqa: E402
+
+BF = torch.bfloat16
+
+
+def ops():
+  from ldm_tf2_amd import ops as _ops
+  return _ops
+
+
+def rnd(shape, seed, scale=1.0):
+  g = torch.Generator().manual_seed(seed)
+  return torch.randn(*shape, generator=g) * scale
+
+
+def rel(got, ref):
+  got, ref = got.detach().float().cpu().double(), ref.detach().double()
+  return ((got - ref).norm() / ref.norm()).item()
+
+
+def _ln_case(M, K, seed, mean_shift):
+  """Rows with a per-row offset (|mean| up to `mean_shift` sigma: the fold subtracts mean * colsum from
+  the accumulated product, so a large mean is the hard case) and per-row scale."""
+  x = rnd((M, K), seed) * (0.5 + torch.rand(M, 1, generator=torch.Generator().manual_seed(seed + 1)) * 2.0)
+  x = x + rnd((M, 1), seed + 2) * mean_shift
+  gamma = 1.0 + 0.3 * rnd((K,), seed + 3)
+  beta = 0.2 * rnd((K,), seed + 4)
+  return x.to(BF), gamma, beta
+
+
+@pytest.mark.parametrize("M,K,N,tile", [
+    (2048, 320, 768, 0),       # q|k at the 32x32 level (N % 128 == 0 -> tile 14)
+    (1000, 320, 768, 14),      # ragged last panel
+    (1024, 1280, 1280, 13),    # 160-column n-tiles, 20 K-tiles
+    (512, 640, 640, 0),        # N % 160 == 0 and N % 128 == 0
+    (768, 64, 256, 0),         # ONE K-tile
+])
+@pytest.mark.parametrize("mean_shift", [0.0, 4.0])
+def test_linear_layernorm_fold(dev, M, K, N, tile, mean_shift):
+  o = ops()
+  x, gamma, beta = _ln_case(M, K, 10, mean_shift)
+  w = rnd((N, K), 20, K ** -0.5)
+  bias = rnd((N,), 21)
+  ref = O.dense(O.layer_norm(x.float(), gamma, beta, eps=1e-5), w.t(), bias)
+  wq, cs, bb = L.ln_fold(w, gamma.numpy(), beta.numpy(), bias.numpy(), BF, dev)
+  out = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+  o.linear(x.to(dev), wq, out, bias=bb, ln_fold=(cs, 1e-5), tile=tile)
+  r = rel(out, ref)
+  # the unfused form on the same inputs (LayerNorm kernel -> bf16 rows -> GEMM) for comparison
+  ln = torch.empty(M, K, dtype=BF, device=dev)
+  o.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), ln, 1e-5)
+  out2 = torch.empty(M, N, dtype=BF, device=dev)
+  o.linear(ln, w.to(BF).to(dev), out2, bias=bias.to(dev))
+  r2 = rel(out2, ref)
+  print(f"LN fold M={M} K={K} N={N} shift={mean_shift}: rel {r:.3e} (LayerNorm kernel + GEMM: {r2:.3e})")
+  # bf16 output rounding is 2^-9 relative per element (rel-L2 ~ 2.3e-3); the fold skips the bf16
+  # rounding of the normalised rows, so it is at least as close as the two-launch form
+  assert r < 4e-3 and r <= r2 * 1.25 + 1e-4
+
+
+def test_linear_layernorm_fold_geglu(dev):
+  """LayerNorm -> GEGLU projection (unet.py:313, :323-325) in one launch."""
+  o = ops()
+  M, C = 1024, 320
+  x, gamma, beta = _ln_case(M, C, 30, 2.0)
+  k_io = rnd((C, 8 * C), 31, C ** -0.5).numpy()
+  b = rnd((8 * C,), 32).numpy()
+  y = O.dense(O.layer_norm(x.float(), gamma, beta, eps=1e-5), torch.from_numpy(k_io), torch.from_numpy(b))
+  ref = y[:, :4 * C] * O.gelu(y[:, 4 * C:])                       # value first, gate second
+  gw, gb = L.geglu_kernel(k_io, b, torch.float32, "cpu")
+  wq, cs, bb = L.ln_fold(gw, gamma.numpy(), beta.numpy(), gb.numpy(), BF, dev)
+  out = torch.full((M, 4 * C), float("nan"), dtype=BF, device=dev)
+  o.linear(x.to(dev), wq, out, bias=bb, act=o.ACT_GEGLU, ln_fold=(cs, 1e-5))
+  r = rel(out, ref)
+  print(f"LN fold + GEGLU: rel {r:.3e}")
+  assert r < 5e-3
+
+
+@pytest.mark.parametrize("R,T,K,N", [(2, 1024, 320, 384), (4, 256, 640, 640), (3, 64, 1280, 1280)])
+def test_linear_t_layernorm_fold(dev, R, T, K, N):
+  """LayerNorm -> V projection stored transposed per sample (the attention kernel's V^T layout)."""
+  o = ops()
+  x, gamma, beta = _ln_case(R * T, K, 40, 3.0)
+  w = rnd((N, K), 41, K ** -0.5)
+  ref = O.dense(O.layer_norm(x.float(), gamma, beta, eps=1e-5), w.t(), None)      # [R*T, N]
+  ref = ref.reshape(R, T, N).permute(0, 2, 1)
+  wq, cs, bb = L.ln_fold(w, gamma.numpy(), beta.numpy(), None, BF, dev)
+  tp = T + 8
+  out = torch.full((R, N, tp), 3.0, dtype=BF, device=dev)
+  o.linear_t(x.reshape(R, T, K).to(dev), wq, out, bias=bb, ln_fold=(cs, 1e-5))
+  r = rel(out[:, :, :T], ref)
+  print(f"LN fold, transposed store R={R} T={T} K={K} N={N}: rel {r:.3e}")
+  assert r < 4e-3
+  assert bool((out[:, :, T:] == 3.0).all())                      # the pad columns are not touched
+
+
+def test_unet_with_folded_layernorm_matches_the_oracle_and_the_unfolded_unet(dev):
+  """A U-Net whose every transformer block takes the fold (fold_min_rows=1) against the oracle, and
+  against the same U-Net with separate LayerNorm launches."""
+  from ldm_tf2_amd.unet import UNet
+  cfg = dict(model_channels=128, out_channels=4, num_blocks=1, channel_mult=(1, 2), num_heads=2)   # heads 64 and 128 -> 160 wide
+  ctx_dim = 128
+  w = Wt.init_weights(Wt.unet_manifest(context_dim=ctx_dim, **cfg), seed=5, mode="random", scope="unet")
+  g = np.random.default_rng(6)
+  x = g.standard_normal((2, 32, 32, 4)).astype(np.float32)
+  ctx = g.standard_normal((2, 77, ctx_dim)).astype(np.float32)
+  t = np.array([981, 21], dtype=np.int32)
+  ref = O.unet_forward(x, t, ctx, w, num_heads=2)
+  outs = {}
+  for fold in (True, False):
+    unet = UNet(**cfg, weights=w, dtype=BF, device=dev, context_dim=ctx_dim, fold_layernorm=fold, fold_min_rows=1)
+    assert (unet.sts[0].fold is not None) == fold
+    outs[fold] = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
+    print(f"tiny U-Net, LayerNorm fold={fold}: rel {rel(outs[fold], ref):.3e}")
+  assert rel(outs[True], ref) < 4e-2 and rel(outs[True], ref) <= rel(outs[False], ref) * 1.5
+
+
+# ---- split-K reduce fused into the consuming GroupNorm (ldm_groupnorm_splitk) ---------------------
+@pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,H,Cin,Cout,split", [(4, 8, 128, 320, 3), (2, 16, 64, 640, 2), (3, 4, 256, 1280, 4),
+                                                (2, 8, 128, 960, 3)])
+def test_splitk_reduce_fused_into_groupnorm(dev, dtype, B, H, Cin, Cout, split):
+  """conv3x3 (split-K, + bias + per-sample addend + residual) -> GroupNorm + SiLU.  The fused launch gives
+  the SAME bits as reduce-then-GroupNorm (same summation order), for the stored product and for the
+  normalised output; both agree with the oracle."""
+  o = ops()
+  x = rnd((B, H, H, Cin), 50).to(dtype)
+  w_hwio = rnd((3, 3, Cin, Cout), 51, (9 * Cin) ** -0.5)
+  bias, temb = rnd((Cout,), 52), rnd((B, Cout), 53)
+  res = rnd((B, H, H, Cout), 54).to(dtype)
+  gamma, beta = 1.0 + 0.3 * rnd((Cout,), 55), 0.2 * rnd((Cout,), 56)
+  wt = L.conv_kernel(w_hwio.numpy(), dtype, dev)
+  xd, resd = x.to(dev), res.to(dev)
+  args = dict(bias=bias.to(dev), addend=temb.to(dev), residual=resd, split_k=split)
+  # reference path: plain split-K conv (reduce launch), then GroupNorm
+  y0 = torch.empty(B, H, H, Cout, dtype=dtype, device=dev)
+  o.conv3x3(xd, wt, y0, **args)
+  g0 = torch.empty_like(y0)
+  o.groupnorm(y0, gamma.to(dev), beta.to(dev), g0, 1e-5, silu=True)
+  # fused path
+  y1 = torch.full((B, H, H, Cout), float("nan"), dtype=dtype, device=dev)
+  pend = o.conv3x3(xd, wt, y1, defer_reduce=True, **args)
+  assert isinstance(pend, o.PendingReduce) and not pend.done
+  with pytest.raises(RuntimeError):                 # the workspace is busy until the product is completed
+    o.conv3x3(xd, wt, torch.empty_like(y0), **args)
+  g1 = torch.empty_like(y0)
+  o.groupnorm(y1, gamma.to(dev), beta.to(dev), g1, 1e-5, silu=True, pending=pend)
+  assert pend.done
+  assert torch.equal(y1, y0) and torch.equal(g1, g0)
+  # store_x=False: the product itself is not written
+  y2 = torch.full((B, H, H, Cout), 7.0, dtype=dtype, device=dev)
+  pend = o.conv3x3(xd, wt, y2, defer_reduce=True, **args)
+  g2 = torch.empty_like(y0)
+  o.groupnorm(y2, gamma.to(dev), beta.to(dev), g2, 1e-5, silu=True, pending=pend, store_x=False)
+  assert torch.equal(g2, g0) and bool((y2 == 7.0).all())
+  # finish(): the plain reduce of a deferred product
+  y3 = torch.empty_like(y0)
+  pend = o.conv3x3(xd, wt, y3, defer_reduce=True, **args)
+  o.finish(pend)
+  assert torch.equal(y3, y0)
+  # oracle
+  yr = O.conv2d(x.float(), w_hwio, bias) + temb[:, None, None, :] + res.float()
+  gr = O.silu(O.group_norm(yr, gamma, beta, eps=1e-5))
+  r = rel(g1, gr)
+  print(f"split-K + GroupNorm fused [{dtype}] B={B} H={H} {Cin}->{Cout} split {split}: rel {r:.3e}")
+  assert r < (2e-5 if dtype == torch.float32 else 1.5e-2)
+
+
+def test_unet_deferred_reduces_equal_the_plain_path(dev):
+  """The U-Net with split-K reduces fused into the consuming GroupNorms gives the same bits as with the
+  separate reduce launches (forced split-K everywhere it can split, so the path is exercised on a tiny model)."""
+  from ldm_tf2_amd.unet import UNet
+  cfg = dict(model_channels=64, out_channels=4, num_blocks=2, channel_mult=(1, 2, 4, 4), num_heads=8)
+  w = Wt.init_weights(Wt.unet_manifest(context_dim=128, **cfg), seed=2, mode="random", scope="unet")
+  g = np.random.default_rng(3)
+  x = g.standard_normal((4, 16, 16, 4)).astype(np.float32)
+  ctx = g.standard_normal((4, 77, 128)).astype(np.float32)
+  t = np.array([981, 981, 21, 500], dtype=np.int32)
+  o = ops()
+  outs = {}
+  for dtype in (torch.float32, BF):
+    for defer in (True, False):
+      unet = UNet(**cfg, weights=w, dtype=dtype, device=dev, context_dim=128, defer_reduce=defer)
+      n_fused = [0]
+      orig = o.lib.ldm_groupnorm_splitk
+
+      def counted(*a, _orig=orig, _n=n_fused):
+        _n[0] += 1
+        return _orig(*a)
+
+      o.lib.ldm_groupnorm_splitk = counted
+      try:
+        outs[(dtype, defer)] = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
+      finally:
+        o.lib.ldm_groupnorm_splitk = orig
+      print(f"tiny U-Net [{dtype}] defer_reduce={defer}: {n_fused[0]} fused reduce+GroupNorm launches")
+      assert (n_fused[0] > 0) == defer
+    assert torch.equal(outs[(dtype, True)], outs[(dtype, False)])
+  ref = O.unet_forward(x, t, ctx, w)
+  assert rel(outs[(torch.float32, True)], ref) < 5e-5
