@@ -367,12 +367,14 @@ def main():
     # HBM-side bytes of the family per U-Net step from the committed PMC passes (same workload;
     # separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE correction applied by tools/pmc_family.py)
     traffic = None
-    tj = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    tjs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+    tj = os.path.join(ROOT, "profiles", tjs[-1]) if tjs else ""     # the latest round's PMC passes
     if args.dtype == "bf16" and lat == 32 and B == 16 and os.path.isfile(tj):
       traffic = json.load(open(tj)).get("hbm_bytes_per_eval")
     roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
-                "traffic_unit": "HBM bytes per U-Net step for this kernel family (PMC, profiles/r02_pmc_traffic.json)",
+                "traffic_unit": ("HBM bytes per U-Net step for this kernel family, from the committed PMC passes of the same "
+                                 f"workload (profiles/{os.path.basename(tj) if tj else '-'}; tools/profile_round.sh reproduces them)"),
                 "kernel": "every launch of ldm_gemm: gemm_kernel<T,BM,BN,WM,WN,MODE,MF,ST> + gemm3_kernel<TN,MODE,EPI> (Dense/1x1/projection GEMMs + implicit-GEMM 3x3 convs) + their split-K reduce",
                 "launches_per_unet_step": n_launches, "ms_per_unet_step_in_kernel": gemm_ms,
                 "avg_launch_us": gemm_ms * 1e3 / max(n_launches, 1),

@@ -108,7 +108,7 @@ typedef struct {
   int32_t dtype;         /* of a, w */
   int32_t out_dtype;     /* of out, residual */
   int32_t split_k;       /* 0 = let the library choose */
-  int32_t tile;          /* 0 = auto; 1-16 force an implicit-GEMM tile (9-12: bf16 16x16x32 MFMA path, 13-14: persistent ping-pong kernel; there split_k < 0 sets the workgroups per row panel, 15-16: tiles 9 / 11 with the halo-staged A operand for stride-1 convolutions whose 256-row M-tile is whole lines of one image, W = 16 or 32), 21-23 the round-1 halo-conv kernel */
+  int32_t tile;          /* 0 = auto; 1-19 force an implicit-GEMM tile (9-12: bf16 16x16x32 MFMA path, 13-14: persistent ping-pong kernel; there split_k < 0 sets the workgroups per row panel, 15-16: tiles 9 / 11 with the halo-staged A operand for stride-1 convolutions whose 256-row M-tile is whole lines of one image, W = 16 or 32, 17-19: the 64x64 / 128x64 / 128x128 tiles with a 4- / 3- / 3-stage LDS ring for launches of 1-3 workgroups per CU), 21-23 the round-1 halo-conv kernel */
   float alpha;
   /* conv prologue (stride-1 halo path only): A := [silu](A*a_scale[b][ci] + a_shift[b][ci]) on
    * in-image pixels, applied ONCE per element in LDS before the zero padding -- the
@@ -257,6 +257,24 @@ int ldm_attention(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64
                   int64_t k_bs, const void* vt, int64_t ldvt, int64_t vt_bs, void* out,
                   int64_t ldo, int64_t o_bs, int batch, int heads, int Tq, int Tk, int Sp,
                   float scale, int dtype, void* stream);
+
+/*
+ * The same attention for bf16 heads of 40 dims padded to Sp = 48, with the softmax bookkeeping moved
+ * onto the matrix cores ("matrix-side softmax"): the caller's projections put the padding to work --
+ *   q : already in the exp2 domain: the query projection's weights carry scale * log2(e) (so the
+ *       scale is applied BEFORE q.k^T here; for bf16 that is a rounding-order difference);
+ *       q[..][h][40..47] = 0
+ *   k : k[..][h][40] = 1.0, k[..][h][41..47] = 0
+ *   vt: row 40 of every head = 1.0 (rows 41..47 = 0); padding COLUMNS [Tk, ldvt) as for ldm_attention
+ * The kernel writes -m (each query's reference point, kept a bf16 number) into dim 40 of its Q
+ * fragments, so K.Q^T returns logit - m, and row 40 of V^T.P^T accumulates the softmax denominator from
+ * the same bf16 P as the numerator.  out[..][h][40..47] = 0.  Same result as ldm_attention up to bf16
+ * rounding (tests/test_round3_gpu.py); 2 of the 5 VALU operations per logit remain.
+ */
+int ldm_attention_ms(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                     int64_t k_bs, const void* vt, int64_t ldvt, int64_t vt_bs, void* out,
+                     int64_t ldo, int64_t o_bs, int batch, int heads, int Tq, int Tk, int Sp,
+                     int dtype, void* stream);
 
 /* Sinusoidal timestep embedding, cos first (unet.py:401-422): out[r][0:half]=cos(t*f),
  * out[r][half:]=sin(t*f), f_k = exp(-ln(10000)*k/half), float32.  t is read from

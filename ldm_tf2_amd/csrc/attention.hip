@@ -83,7 +83,20 @@ template <> struct AttnTraits<float> {
 // per LDS tile.  The O^T accumulator is built from 32-row MFMA tiles, so when SP is not a
 // multiple of 32 the last tile's upper rows read unstaged LDS: they only ever feed output
 // rows >= SP, which are never stored.
-template <typename T, int SP, int KT>
+// MS ("matrix-side softmax", bf16, SP = 48 for the 40-wide heads): the padded head dims are put to work.
+//   * dim RD = 40 of K holds 1.0 and dim RD of Q holds -m (the query's current reference point, a bf16
+//     value), and the logits arrive in the exp2 domain (scale * log2(e) folded into the query
+//     projection's weights): the first MFMA returns  q.k * scale * log2(e) - m  directly -- no fma per
+//     logit;
+//   * row RD of V^T holds 1.0: row RD of O^T accumulates sum_k P[k], the softmax denominator, from the
+//     same bf16 P the numerator uses -- no add per logit.
+// Per logit that leaves max + exp2 (+ the bf16 pack): the d = 40 self-attention was VALU-bound with
+// 704 softmax cycles against 448 MFMA cycles per 64-key tile and wave.  The ones in K / V^T come from the
+// producing projections' biases (the host puts 1.0 into the padded rows), -m is written into the Q
+// fragment in registers; the reference only moves when some query's tile maximum exceeds it by 2^8
+// (as before), and then by an amount that keeps it a bf16 number, so numerator and denominator see
+// exactly the same reference.
+template <typename T, int SP, int KT, bool MS = false>
 // Waves per SIMD: the softmax (VALU, exp2) and the two MFMA phases of different waves overlap,
 // so residency pays: measured 130 -> 109 -> 91 us at T = 1024, Sp = 48 for 2 -> 3 -> 4 waves per
 // SIMD (5 spills 144 bytes per lane and loses again); the wide heads keep the compiler's choice.
@@ -129,7 +142,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
   for (int d = 0; d < ND; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;          // running max (log2 domain) and sum
+  constexpr int RD = 40;                         // MS: the padded head dim that carries -m / 1 / the row sums
+  static_assert(!MS || (sizeof(T) == 2 && SP == 48), "matrix-side softmax: bf16, 40-wide heads padded to 48");
+  float m_run = MS ? 0.f : -INFINITY, l_run = 0.f;   // running max (log2 domain) and sum; MS: Q[RD] = -0 initially
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
 
   u32x4 rk[CK], rv[CV];
@@ -210,6 +225,44 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
           if (key >= p.Tk) s[j][r] = -INFINITY;
         }
     }
+    if constexpr (MS) {
+      // s = logit - m_run already (exp2 domain)
+      float mt = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mt = fmaxf(fmaxf(mt, s[j][r]), s[j][r + 1]);   // v_max3_f32
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      if (t == 0 || !__all(mt <= 8.0f)) {   // wave-uniform
+        // move the reference: to the first tile's maximum (either direction), afterwards only up
+        const float want = m_run + (t == 0 ? mt : fmaxf(mt, 0.f));
+        const float m_new = bf2f(f2bf(want));                 // the reference stays a bf16 number
+        const float delta = m_new - m_run;                    // exact (difference of two bf16 numbers)
+        m_run = m_new;
+        if (t > 0) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;    // (row RD, the denominator, included)
+        }
+#pragma unroll
+        for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[j][r] -= delta;
+        // Q fragment element of dim RD: k group RD / 16, lane half (RD % 16) / 8, element RD % 8
+        if (lh == (RD % 16) / 8) {
+          uint32_t w = qf[RD / 16][(RD % 8) / 2];
+          const uint32_t nb = (uint32_t)f2bf(-m_new);
+          w = (RD % 2) ? ((w & 0x0000ffffu) | (nb << 16)) : ((w & 0xffff0000u) | nb);
+          qf[RD / 16][(RD % 8) / 2] = w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NSUB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[j][r] = __builtin_amdgcn_exp2f(s[j][r]);
+    } else {
     float mt = -INFINITY;
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)
@@ -236,6 +289,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
         ls += e;
       }
     l_run += ls;
+    }
     // ---- O^T += V^T . P^T -------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < NSUB; ++j)
@@ -251,7 +305,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
       }
   }
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if constexpr (MS) {
+    // row RD of O^T: tile RD / 32, tile row RD % 32 = (r & 3) + 8 (r >> 2) + 4 lh -> lanes with lh = 0
+    constexpr int RR = RD % 32;
+    static_assert((RR % 8) < 4, "row RD must live in the lh = 0 half");
+    l_tot = __shfl(o[RD / 32][(RR % 4) + 4 * (RR / 8)], lane & 31, 64);
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / l_tot;
   const int qi = q0 + lr;
   if (qi < p.Tq) {
@@ -265,6 +327,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = o[d][r4 * 4 + e] * inv;
+        if constexpr (MS) {                         // the denominator's row is padding of the output: zero
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (dim + e == RD) ? 0.f : v[e];
+        }
         if constexpr (sizeof(T) == 2) {
           u32x2 pk; pk[0] = pack_bf2(v[0], v[1]); pk[1] = pack_bf2(v[2], v[3]);
           *(u32x2*)(orow + dim) = pk;
@@ -498,6 +564,26 @@ int launch_attn(const AttnArgs& a, int Sp, dim3 grid, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" int ldm_attention_ms(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
+                                int64_t k_bs, const void* vt, int64_t ldvt, int64_t vt_bs, void* out,
+                                int64_t ldo, int64_t o_bs, int batch, int heads, int Tq, int Tk, int Sp,
+                                int dtype, void* stream) {
+  LDM_CHECK_ARG(q && k && vt && out, "ldm_attention_ms: null pointer");
+  LDM_CHECK_ARG(dtype == LDM_BF16 && Sp == 48, "ldm_attention_ms: bf16 with 40-wide heads padded to 48 only");
+  LDM_CHECK_ARG(batch > 0 && heads > 0 && Tq > 0 && Tk > 0 && batch < 65536 && heads < 65536, "ldm_attention_ms: bad dims");
+  LDM_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldvt % 8 == 0 && ldo % 8 == 0 && q_bs % 8 == 0 && k_bs % 8 == 0 &&
+                    vt_bs % 8 == 0 && o_bs % 8 == 0 && ldvt >= Tk, "ldm_attention_ms: strides must be multiples of 8 elements, ldvt >= Tk");
+  LDM_CHECK_ARG(((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0 && ((uintptr_t)vt % 16) == 0 &&
+                    ((uintptr_t)out % 16) == 0, "ldm_attention_ms: pointers must be 16-byte aligned");
+  AttnArgs a;
+  a.q = (const char*)q; a.k = (const char*)k; a.vt = (const char*)vt; a.out = (char*)out;
+  a.ldq = ldq; a.q_bs = q_bs; a.ldk = ldk; a.k_bs = k_bs; a.ldvt = ldvt; a.vt_bs = vt_bs;
+  a.ldo = ldo; a.o_bs = o_bs; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.scale = 1.0f;
+  dim3 grid((Tq + 127) / 128, heads, batch);
+  hipLaunchKernelGGL((attn_kernel<bf16_t, 48, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  return ldm_launch_status("ldm_attention_ms");
+}
 
 extern "C" int ldm_attention(const void* q, int64_t ldq, int64_t q_bs, const void* k, int64_t ldk,
                              int64_t k_bs, const void* vt, int64_t ldvt, int64_t vt_bs, void* out,

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(GemmArgs p) {
 
 struct TileCfg { int bm, bn; };
 // index 1..4 (0 = auto)
-constexpr int kNumTiles = 17;
+constexpr int kNumTiles = 20;
 constexpr TileCfg kTiles[kNumTiles] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}, {64, 64}, {256, 128},
                                        {128, 160}, {256, 160}, {128, 320},    // 6-8: N = 160*k layers
                                        // 9-12: bf16 v_mfma_f32_16x16x32 path, wave tiles 64 x 80 / 64 x 64;
@@ -164,10 +164,13 @@ constexpr TileCfg kTiles[kNumTiles] = {{0, 0}, {256, 128}, {128, 128}, {128, 64}
                                        {256, 160}, {256, 128},
                                        // 15, 16: tiles 9 / 11 with the HALO-STAGED A operand (gemm_kernel.h MODE 3):
                                        // stride-1 convolutions whose M-tile is whole lines of one image
-                                       {256, 160}, {256, 128}};
-constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2, 1, 1, 1, 1};   // workgroups per CU (LDS-limited)
+                                       {256, 160}, {256, 128},
+                                       // 17-19: tiles 4 / 3 / 2 with a deeper LDS ring (4 / 3 / 3 stages): launches of
+                                       // 1-3 workgroups per CU, where nothing else covers the per-K-tile round trip
+                                       {64, 64}, {128, 64}, {128, 128}};
+constexpr int kResident[kNumTiles] = {0, 1, 2, 3, 5, 1, 2, 1, 1, 1, 2, 1, 2, 1, 1, 1, 1, 2, 2, 1};   // workgroups per CU (LDS-limited)
 constexpr bool kBf16Only[kNumTiles] = {false, false, false, false, false, false, false, false, false, true, true, true, true, true, true,
-                                       true, true};
+                                       true, true, false, false, false};
 constexpr bool is_persistent(int c) { return c == 13 || c == 14; }
 constexpr bool is_halo_ring(int c) { return c == 15 || c == 16; }
 // MODE 3 geometry: stride 1, pad 1, no upsample, the 256-row M-tile = 256 / W whole lines of ONE image
@@ -196,8 +199,8 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // measured time one CU needs for one K-tile of that configuration with its resident
 // workgroups co-running.  Split-K adds the f32 partial round trip + one more launch.
 void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
-  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80, 1.03, 0.97, 1.0, 0.94};   // bf16, per round per K-tile (resident WGs co-running)
-  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 9, 9};   // launch + prologue + epilogue, in K-tiles
+  static const double kStepUs[kNumTiles] = {0, 0.82, 0.82, 0.75, 0.87, 0.82, 1.12, 1.18, 1.15, 1.03, 1.09, 0.97, 0.80, 1.03, 0.97, 1.0, 0.94, 0.87, 0.75, 0.82};   // bf16, per round per K-tile (resident WGs co-running)
+  static const double kOverheadSteps[kNumTiles] = {0, 8, 8, 7, 6, 8, 8, 8, 8, 8, 8, 8, 8, 4, 4, 9, 9, 6, 7, 8};   // launch + prologue + epilogue, in K-tiles
   static const int kSplits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16, 20, 24, 32};
 #ifdef LDM_TOOLS_BUILD
   static const bool no160 = getenv("LDM_GEMM_NO160") != nullptr;   // A/B switch, tools build only
@@ -214,14 +217,14 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   for (int c = 1; c < kNumTiles; ++c) {
     if (p->tile > 0 && p->tile < kNumTiles && c != p->tile) continue;
     if (c == 5 && p->tile != 5) continue;   // experimental: only when forced
-    if (c >= 13 && p->tile != c) continue;   // persistent kernel, halo-staged conv tiles: only when forced (plan tables)
+    if (c >= 13 && p->tile != c) continue;   // persistent kernel, halo-staged conv tiles, deep-ring small tiles: only when forced (plan tables)
     if (c == 12 && p->tile != c) continue;   // 128x128 on the 16x16x32 path: no better than tile 2, only when forced
     if ((c == 1 || c == 7) && esize == 2 && p->tile != c) continue;   // bf16: their ping-ponged twins 11 / 9 are ~20 % faster
     if (c == 6 && esize == 2 && p->tile != 6) continue;   // bf16: tile 10 (same 128x160 tile, 64x80 wave tiles) is 10-14 % faster
     if (kBf16Only[c] && esize != 2) continue;
     if (kTiles[c].bn % 160 == 0 && p->tile != c && (p->N % kTiles[c].bn != 0 || no160)) continue;   // 160/320-column tiles: N = 160*k layers
     if (p->out2 && p->n_split % kTiles[c].bn != 0) continue;                        // every tile on one side of n_split
-    if (geglu && c > 2 && c != 5 && c != 11 && c != 12 && c != 14) continue;
+    if (geglu && c > 2 && c != 5 && c != 11 && c != 12 && c != 14 && c != 19) continue;
     const TileCfg t = kTiles[c];
     const double tiles = (double)cdiv(p->M, t.bm) * cdiv(p->N, t.bn) * p->batch;
     for (int split : kSplits) {
@@ -441,7 +444,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     LDM_CHECK_ARG(p->rows2 > 0 && p->rows2 % 4 == 0 && p->M % p->rows2 == 0 && p->ld2 % 4 == 0 && p->stride2 % 4 == 0 &&
                       ((uintptr_t)p->out2 % 16) == 0, "ldm_gemm: out2 geometry (rows2 %% 4, M %% rows2, ld2 / stride2 %% 4, alignment)");
   }
-  if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5 || cfg == 11 || cfg == 12 || cfg == 14, "ldm_gemm: GEGLU needs a tile whose width is a multiple of 64 (1, 2, 5, 11, 12)");
+  if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5 || cfg == 11 || cfg == 12 || cfg == 14 || cfg == 19, "ldm_gemm: GEGLU needs a tile whose width is a multiple of 64 (1, 2, 5, 11, 12)");
   LDM_CHECK_ARG(!kBf16Only[cfg] || esize == 2, "ldm_gemm: tile %d is bf16 only", cfg);
   if (is_halo_ring(cfg))
     LDM_CHECK_ARG(halo_ring_ok(p) && p->N % kTiles[cfg].bn == 0 && !p->out2 && !p->ln_out,

@@ -109,7 +109,12 @@ __device__ __forceinline__ float apply_act(int act, float v) {
 //           barrier period, waves 4-7 run {MFMA tile t-1 (fragments kept in registers across the
 //           barrier), stage, read fragments of tile t}: on each SIMD one wave multiplies while the
 //           other stages and reads LDS, instead of both doing the same thing at the same time.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int MF = 0, int ST = 0>
+// NS:   0 = ring depth chosen below (2, or 3 on the one-workgroup-per-CU 8-wave tiles); 3 / 4 = a deeper ring on
+//           the SMALL tiles (tiles 17-19).  A 64x64 / 128x64 launch with 5-20 K-tiles and a 2-deep ring pays one
+//           L2 round trip per K-tile; with only 1-3 workgroups per CU (M <= 4096: the batch-8-per-GPU step) nothing
+//           else covers it, so NS - 1 tiles in flight pay where residency does not (round 2 measured the deeper
+//           rings slower at >= 5 workgroups per CU, where the LDS they cost evicts a resident workgroup).
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int MF = 0, int ST = 0, int NS = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // The body uses LDS address-space pointers and gfx950 inline asm, which only the
   // device pass can parse; the host pass just needs the launch stub.
@@ -139,7 +144,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // A third stage (prefetch distance 2) only where it is free: tiles whose two stages already
   // leave room for just one workgroup per CU (160 KB LDS) and whose three stages still fit.
   constexpr int kLds = 160 * 1024;
-  constexpr int NSTAGE = RING ? 3 : (4 * STAGE > kLds && 3 * STAGE <= kLds && WM * WN == 8) ? 3 : 2;
+  constexpr int NSTAGE = NS ? NS : RING ? 3 : (4 * STAGE > kLds && 3 * STAGE <= kLds && WM * WN == 8) ? 3 : 2;
+  static_assert(NSTAGE >= 2 && NSTAGE <= 4 && (!NS || (!RING && !ST)), "ring depth");
   constexpr int RINGB = RING ? 2 * PATCH : 0;      // bytes of the two halo patches in front of the weight ring
   // the 160/320-column tiles stage their f32 epilogue tile in two row passes (LDS budget)
   constexpr int ESPLIT = (BN % 160 == 0 && WM >= 2) ? 2 : 1;
@@ -380,11 +386,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // LDS-DMAs may still be in flight -- and tile t+2 goes to the stage tile t-1 was read from.
   if constexpr (!RING) {
     if (nk > 0) issue_tile(kt_begin, 0);
-    if (NSTAGE == 3 && nk > 1) issue_tile(kt_begin + 1, 1);
+    if (NSTAGE >= 3 && nk > 1) issue_tile(kt_begin + 1, 1);
+    if (NSTAGE >= 4 && nk > 2) issue_tile(kt_begin + 2, 2);
   }
   u32x4 fa[KS][TM], fb[KS][TN];
-  auto wait_tile = [&](int t) {                      // this wave's LDS-DMAs of tile t have landed
-    if (NSTAGE == 3 && t + 1 < nk) {
+  // this wave's LDS-DMAs of tile t have landed: the younger tiles t+1 .. t+NSTAGE-2 (as far as they
+  // exist) may stay in flight -- a counted wait of (tiles in flight) x (this wave's loads per tile)
+  auto wait_tile = [&](int t) {
+    const int ahead = min(NSTAGE - 2, nk - 1 - t);   // wave-uniform
+    if (NSTAGE >= 4 && ahead == 2) {
+      if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NL) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (NL - 1)) : "memory");
+    } else if (NSTAGE >= 3 && ahead == 1) {
       if (b_last) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL - 1) : "memory");
     } else {

@@ -29,6 +29,10 @@ void launch_cfg(int cfg, const GemmArgs& a, dim3 grid, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE, 1>), grid, dim3(256), 0, s, a);                    // 4 waves x (64x64), 2 workgroups per CU
       }
       break;
+    // 17-19: the small tiles with a deeper LDS ring (gemm_kernel.h NS): for launches of 1-3 workgroups per CU
+    case 17: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, MODE, 0, 0, 4>), grid, dim3(256), 0, s, a); break;
+    case 18: hipLaunchKernelGGL((gemm_kernel<T, 128, 64, 2, 2, MODE, 0, 0, 3>), grid, dim3(256), 0, s, a); break;
+    case 19: hipLaunchKernelGGL((gemm_kernel<T, 128, 128, 2, 2, MODE, 0, 0, 3>), grid, dim3(256), 0, s, a); break;
     default: hipLaunchKernelGGL((gemm_kernel<T, 64, 64, 2, 2, MODE>), grid, dim3(256), 0, s, a); break;
   }
 }

@@ -72,14 +72,33 @@ def geglu_kernel(k_io, bias, dtype, device):
   return _dev(inter, dtype, device), _dev(bi, torch.float32, device)
 
 
-def ln_fold(wt_nk, gamma, beta, bias, dtype, device):
+MS_DIM = 40        # the padded head dim ldm_attention_ms uses (heads of 40 padded to 48)
+MS_LOG2E = 1.4426950408889634
+
+
+def ms_ones(heads, sp, offset=0, total=None):
+  """float32 vector with 1.0 at dim MS_DIM of every head (rows offset + h*sp + MS_DIM), else 0."""
+  v = torch.zeros(total if total is not None else offset + heads * sp, dtype=torch.float32)
+  v[offset + MS_DIM: offset + heads * sp: sp] = 1.0
+  return v
+
+
+def ln_fold(wt_nk, gamma, beta, bias, dtype, device, row_scale=None, bias_extra=None):
   """LayerNorm -> Dense folded for ldm_gemm's `ln_cs` form (include/ldm_hip.h): from the device-layout
   float32 matrix wt [N, K] (rows = outputs), the LayerNorm's gamma / beta [K] and the Dense bias [N]
   (or None) returns (w', cs, b') on the device with
       w' = dtype(gamma (.) W),  cs[n] = sum_k float(w'[n, k]),  b' = bias + W beta   (float32),
   so that LN(x) W^T + bias = rstd (x w'^T - mean cs) + b'.  cs is summed from the ROUNDED w' (what
-  the MFMA multiplies), in float64, so that the mean term cancels exactly what the product carries."""
+  the MFMA multiplies), in float64, so that the mean term cancels exactly what the product carries.
+  `row_scale` [N]: every output n (weights and bias) is multiplied by row_scale[n] first (the attention
+  scale folded into the query projection); `bias_extra` [N] is added to b' last (the 1.0 of the padded
+  head rows that ldm_attention_ms uses)."""
   w = wt_nk.detach().to("cpu", torch.float32)
+  if row_scale is not None:
+    rs = torch.as_tensor(np.asarray(row_scale), dtype=torch.float32)
+    w = w * rs[:, None]
+    if bias is not None:
+      bias = np.asarray(bias, dtype=np.float32) * rs.numpy()
   g = torch.as_tensor(np.asarray(gamma), dtype=torch.float32)
   b = torch.as_tensor(np.asarray(beta), dtype=torch.float32)
   wq = (w * g[None, :]).to(dtype)
@@ -87,6 +106,8 @@ def ln_fold(wt_nk, gamma, beta, bias, dtype, device):
   bb = (w.to(torch.float64) @ b.to(torch.float64)).to(torch.float32)
   if bias is not None:
     bb = bb + torch.as_tensor(np.asarray(bias), dtype=torch.float32)
+  if bias_extra is not None:
+    bb = bb + torch.as_tensor(np.asarray(bias_extra), dtype=torch.float32)
   return wq.contiguous().to(device), cs.contiguous().to(device), bb.contiguous().to(device)
 
 

@@ -148,7 +148,8 @@ _TILE_DIMS = {1: (256, 128, 1), 2: (128, 128, 2), 3: (128, 64, 3), 4: (64, 64, 5
               7: (256, 160, 1), 8: (128, 320, 1),       # BM, BN, resident workgroups per CU
               9: (256, 160, 1), 10: (128, 160, 2), 11: (256, 128, 1), 12: (128, 128, 2),   # bf16 16x16x32 MFMA path
               13: (256, 160, 1), 14: (256, 128, 1),     # persistent ping-pong kernel (no split-K, N % BN == 0)
-              15: (256, 160, 1), 16: (256, 128, 1)}     # tiles 9 / 11 with the halo-staged A operand (stride-1 convs)
+              15: (256, 160, 1), 16: (256, 128, 1),     # tiles 9 / 11 with the halo-staged A operand (stride-1 convs)
+              17: (64, 64, 2), 18: (128, 64, 2), 19: (128, 128, 1)}   # tiles 4 / 3 / 2 with a 4- / 3- / 3-stage LDS ring
 _BF16_TILES = (9, 10, 11, 12, 13, 14, 15, 16)
 _PERSISTENT_TILES = (13, 14)
 _HALO_RING_TILES = (15, 16)
@@ -272,7 +273,7 @@ def plan_candidates(M, N, K, batch, act, dtype, key=None):
   for tile, (bm, bn, res) in _TILE_DIMS.items():
     if tile in _HALO_RING_TILES and not (dtype == BF16 and batch == 1 and _halo_ring_key(key, M, N, bn)):
       continue
-    if act == ACT_GEGLU and tile not in (1, 2, 11, 12, 14):
+    if act == ACT_GEGLU and tile not in (1, 2, 11, 12, 14, 19):
       continue
     if tile in _BF16_TILES and dtype != BF16:
       continue
@@ -665,12 +666,20 @@ def softmax_rows(x, out, scale=1.0):
   return out
 
 
-def attention(q, k, vt, out, heads, sp, scale):
-  """q [R, Tq, heads*sp], k [R, Tk, heads*sp], vt [R, heads*sp, ldvt>=Tk], out like q."""
+def attention(q, k, vt, out, heads, sp, scale, matrix_softmax=False):
+  """q [R, Tq, heads*sp], k [R, Tk, heads*sp], vt [R, heads*sp, ldvt>=Tk], out like q.
+  `matrix_softmax`: ldm_attention_ms (bf16, 40-wide heads padded to 48): q pre-scaled into the exp2
+  domain, k[..., 40] = 1 and V^T row 40 = 1 per head (layout.MS_DIM; the projections' biases put them
+  there), `scale` is not used."""
   R, Tq = q.shape[0], q.shape[1]
   Tk = k.shape[1]
   assert q.dtype == k.dtype == vt.dtype == out.dtype
   assert vt.shape[1] == heads * sp and vt.stride(2) == 1
+  if matrix_softmax:
+    check(lib.ldm_attention_ms(_ptr(q), q.stride(1), q.stride(0), _ptr(k), k.stride(1), k.stride(0),
+                               _ptr(vt), vt.stride(1), vt.stride(0), _ptr(out), out.stride(1),
+                               out.stride(0), R, heads, Tq, Tk, sp, code(q.dtype), _stream()), "ldm_attention_ms")
+    return out
   check(lib.ldm_attention(_ptr(q), q.stride(1), q.stride(0), _ptr(k), k.stride(1), k.stride(0),
                           _ptr(vt), vt.stride(1), vt.stride(0), _ptr(out), out.stride(1),
                           out.stride(0), R, heads, Tq, Tk, sp, float(scale), code(q.dtype),

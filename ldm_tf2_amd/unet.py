@@ -53,7 +53,7 @@ class _Res:
 class _ST:
   """SpatialTransformer weights (unet.py:341-354, :295-306, :248-265, :317-338)."""
 
-  def __init__(self, w, p, heads, dtype, dev, fold_ln=False):
+  def __init__(self, w, p, heads, dtype, dev, fold_ln=False, matrix_softmax=True):
     g = lambda n: w[p + "/" + n]
     c = g("dense1/kernel").shape[0]
     self.c, self.heads = c, heads
@@ -79,16 +79,31 @@ class _ST:
                for i in (1, 2, 3)]
     # bf16: the three LayerNorms folded into the projections they feed (ldm_gemm ln_cs): (w', cs, b')
     self.fold = None
+    # matrix-side softmax (ldm_attention_ms): 40-wide heads padded to 48, together with the fold (the
+    # folded projections' biases carry the ones of the padded rows, their weights the exp2-domain scale)
+    self.ms = bool(fold_ln and matrix_softmax and self.s == L.MS_DIM and sp == 48)
+    self.ms_kbias = self.ms_vbias = None
     if fold_ln:
       lnp = [(g(f"block/layernorm{i}/gamma"), g(f"block/layernorm{i}/beta")) for i in (1, 2, 3)]
       f32, cpu = torch.float32, "cpu"
+      hs = heads * sp
       qk_f = torch.cat([L.split_kernel(w[a1 + "/query/kernel"], sp, f32, cpu),
                         L.split_kernel(w[a1 + "/key/kernel"], sp, f32, cpu)], 0)
       gw, gb = L.geglu_kernel(g("block/ffn/geglu/kernel"), g("block/ffn/geglu/bias"), f32, cpu)
+      qk_scale = qk_ones = v_ones = q_scale = None
+      if self.ms:
+        c2 = float(self.s) ** -0.5 * L.MS_LOG2E                  # unet.py:281 scale, in the exp2 domain
+        qk_scale = torch.cat([torch.full((hs,), c2), torch.ones(hs)])
+        qk_ones = L.ms_ones(heads, sp, offset=hs)                 # K[..., 40] = 1
+        v_ones = L.ms_ones(heads, sp)                             # V^T row 40 = 1
+        q_scale = torch.full((hs,), c2)
+        self.ms_kbias, self.ms_vbias = v_ones.to(dev), v_ones.clone().to(dev)     # cross-attention K / V of the context
       self.fold = dict(
-          qk1=L.ln_fold(qk_f, lnp[0][0], lnp[0][1], None, dtype, dev),
-          v1=L.ln_fold(L.split_kernel(w[a1 + "/value/kernel"], sp, f32, cpu), lnp[0][0], lnp[0][1], None, dtype, dev),
-          q2=L.ln_fold(L.split_kernel(w[a2 + "/query/kernel"], sp, f32, cpu), lnp[1][0], lnp[1][1], None, dtype, dev),
+          qk1=L.ln_fold(qk_f, lnp[0][0], lnp[0][1], None, dtype, dev, row_scale=qk_scale, bias_extra=qk_ones),
+          v1=L.ln_fold(L.split_kernel(w[a1 + "/value/kernel"], sp, f32, cpu), lnp[0][0], lnp[0][1], None, dtype, dev,
+                       bias_extra=v_ones),
+          q2=L.ln_fold(L.split_kernel(w[a2 + "/query/kernel"], sp, f32, cpu), lnp[1][0], lnp[1][1], None, dtype, dev,
+                       row_scale=q_scale),
           geglu=L.ln_fold(gw, lnp[2][0], lnp[2][1], gb.numpy(), dtype, dev))
     self.ctx_k = self.ctx_vt = None     # filled by UNet.set_context
 
@@ -104,7 +119,7 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True):
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -129,6 +144,8 @@ class UNet:
     # on the persistent kernel (fold_min_rows); float32 keeps the separate LayerNorm (parity mode).
     self._fold_ln = dtype == torch.bfloat16 and bool(fold_layernorm) and not self._fuse_ln
     self._fold_min_rows = int(fold_min_rows)
+    self._matrix_softmax = bool(matrix_softmax)   # ldm_attention_ms on the 40-wide heads (with the fold; A/B: False)
+    self._gn_single = bool(gn_single_launch)      # False: partial-sums + apply launches everywhere (A/B)
     self._defer_reduce = bool(defer_reduce)   # split-K reduces fused into the consuming GroupNorm (A/B: False)
     self._pend = None
     self._fuse_cache = {}
@@ -166,7 +183,8 @@ class UNet:
       return r
 
     def mk_st(p):
-      return _ST(w, p, H, dt, dev, fold_ln=self._fold_ln) if (p + "/dense1/kernel") in w else None
+      return (_ST(w, p, H, dt, dev, fold_ln=self._fold_ln, matrix_softmax=self._matrix_softmax)
+              if (p + "/dense1/kernel") in w else None)
 
     self.in_blocks, self.skip_ch, self.skip_lvl = [], [mc], [0]
     lvl, i = 0, 0
@@ -233,8 +251,10 @@ class UNet:
         hs = st.heads * st.sp
         st.ctx_k = self.buf.get(f"ctxk{n}", (R, Tk, hs), self.dtype)
         st.ctx_vt = self.buf.get(f"ctxv{n}", (R, hs, tkp), self.dtype, zero=True)
-        ops.linear(context, st.k2, st.ctx_k)
-        ops.bmm_nt(context, st.v2, st.ctx_vt, transposed_out=True)
+        # (matrix-side softmax blocks: 1.0 in the padded dim 40 of every head of K and V^T; inert for
+        # the plain attention kernel, whose Q is zero there)
+        ops.linear(context, st.k2, st.ctx_k, bias=st.ms_kbias)
+        ops.bmm_nt(context, st.v2, st.ctx_vt, transposed_out=True, bias=st.ms_vbias)
     self._ctx_rows = R
 
   # ---- blocks ------------------------------------------------------------------------------
@@ -284,7 +304,8 @@ class UNet:
 
   def _gn(self, x, gn, eps, silu, out, store_x=True):
     pend, self._pend = self._pend, None
-    ops.groupnorm(x, gn[0], gn[1], out, eps, silu=silu, partial=self._gnp, pending=pend, store_x=store_x)
+    ops.groupnorm(x, gn[0], gn[1], out, eps, silu=silu, partial=self._gnp, pending=pend, store_x=store_x,
+                  fused=None if self._gn_single else False)
     return out
 
   def _res(self, r, x, tall, out):
@@ -354,7 +375,8 @@ class UNet:
       ops.linear(ln, st.qk1, qk)
       ops.bmm_nt(ln, st.v1, vt, transposed_out=True)
     att = B_.get("st_att", (R, T, hs), dt)
-    ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale)
+    ms = fold is not None and st.ms
+    ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
     hb = B_.get("st_b", (R, T, c), dt)
     ops.linear(att, st.o1[0], hb, bias=st.o1[1], residual=ha, ln=lnp(1))
     # cross-attention (unet.py:311-312)
@@ -365,7 +387,7 @@ class UNet:
       if not fuse_ln:
         ops.layernorm(hb, st.ln[1][0], st.ln[1][1], ln, LN_EPS)
       ops.linear(ln, st.q2, q)
-    ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale)
+    ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
     ops.linear(att, st.o2[0], ha, bias=st.o2[1], residual=hb, ln=lnp(2))
     # GEGLU feed-forward (unet.py:313, :323-325, :335-338)
     ff = B_.get("st_ff", (R, T, 4 * c), dt)

@@ -36,7 +36,7 @@ def close(got, ref, dtype, scale=1.0):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 17, 18, 19])
 @pytest.mark.parametrize("M,N,K", [(300, 320, 320), (64, 192, 1280), (1024, 64, 64), (700, 640, 128)])
 def test_linear(dev, dtype, tile, M, N, K):
   if tile >= 9 and dtype != torch.bfloat16:
@@ -70,6 +70,13 @@ def test_linear_act_splitk(dev, dtype, act):
     out = torch.zeros(M, nout, dtype=dtype, device=dev)
     o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), act=code, split_k=split)
     close(out, ref, dtype)
+  # deep-ring small tiles (17-19): every activation epilogue, with and without split-K (K = 2560: 40 / 80
+  # K-tiles, the ring runs full; split 5 leaves 8 / 16 per slab)
+  for tile in ((19,) if act == "geglu" else (17, 18, 19)):
+    for split in (1, 5):
+      out = torch.zeros(M, nout, dtype=dtype, device=dev)
+      o.linear(x.to(dev), w.to(dev), out, bias=bias.to(dev), act=code, split_k=split, tile=tile)
+      close(out, ref, dtype)
   if dtype == torch.bfloat16:
     # 16x16x32 MFMA tiles: every activation epilogue and the split-K slab layout
     for tile in ((11, 12) if act == "geglu" else (9, 10, 11, 12)):
@@ -116,7 +123,7 @@ def test_conv3x3(dev, dtype, cfg):
   ref = ref + res.float()
   wt = k.permute(3, 0, 1, 2).reshape(Cout, 9 * Cin).contiguous().to(dev)
   bf = (9, 10, 11, 12) if dtype == torch.bfloat16 else ()     # 16x16x32 MFMA tiles: bf16 only
-  for tile in (0, 1, 2, 3, 4, 6, 7, 8) + bf + (21, 22, 23):     # 1-11 implicit GEMM tiles, 21-23 halo tiles
+  for tile in (0, 1, 2, 3, 4, 6, 7, 8) + bf + (17, 18, 19, 21, 22, 23):   # implicit GEMM tiles (17-19: deep rings), 21-23 halo tiles
     out = torch.zeros(B, OH, OW, Cout, dtype=dtype, device=dev)
     o.conv3x3(x.to(dev), wt, out, bias=bias.to(dev), stride=cfg["stride"], upsample=cfg["up"],
               addend=addend.to(dev), residual=res.to(dev), tile=tile)

@@ -83,9 +83,9 @@ def test_candidates_respect_tile_rules():
   c = ops.plan_candidates(512, 1280, 11520, 1, ops.ACT_NONE, ops.BF16)                 # 4x4 conv: split-K matters
   assert (1, 12) in c and (2, 12) in c and (6, 4) in c
   c = ops.plan_candidates(32768, 2560, 320, 1, ops.ACT_GEGLU, ops.BF16)
-  assert {t for t, _ in c} == {1, 2, 11, 12, 14}                                                # GEGLU: 64-column interleave
+  assert {t for t, _ in c} == {1, 2, 11, 12, 14, 19}                                                # GEGLU: 64-column interleave
   c = ops.plan_candidates(8192, 1536, 640, 1, ops.ACT_NONE, ops.BF16)
-  assert all(t < 6 or t in (11, 12, 14) for t, _ in c)                                            # N % 160 != 0
+  assert all(t < 6 or t in (11, 12, 14, 17, 18, 19) for t, _ in c)                                            # N % 160 != 0
   assert all(t not in (9, 10, 11, 12, 13, 14) for t, _ in ops.plan_candidates(8192, 640, 640, 1, ops.ACT_NONE, ops.F32))   # bf16-only tiles
 
 
@@ -96,7 +96,7 @@ def test_packaged_plans_are_legal():
     plans = json.load(open(path))["plans"]
     for key, (tile, split) in plans.items():
       f = dict((k.rstrip("0123456789"), int(k[len(k.rstrip("0123456789")):])) for k in key.split())
-      assert tile in (1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16) and split >= 1, (path, key)
+      assert tile in (1, 2, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19) and split >= 1, (path, key)
       assert (tile, split) in ops.plan_candidates(f["M"], f["N"], f["K"], f["b"], f["act"], f["dt"], key=key), (path, key)
       # the library accepts the forced pair for planning purposes
       p = _params(f["M"], f["N"], f["K"], conv=f["conv"], act=f["act"], dtype=f["dt"])

@@ -211,3 +211,63 @@ def test_unet_deferred_reduces_equal_the_plain_path(dev):
     assert torch.equal(outs[(dtype, True)], outs[(dtype, False)])
   ref = O.unet_forward(x, t, ctx, w)
   assert rel(outs[(torch.float32, True)], ref) < 5e-5
+
+
+# ---- matrix-side softmax attention (ldm_attention_ms) -----------------------------------------------
+def _ms_case(dev, R, H, Tq, Tk, spike=False, big_offset=0.0):
+  o = ops()
+  S, sp = 40, 48
+  q = rnd((R, Tq, H, S), 60)
+  k = rnd((R, Tk, H, S), 61)
+  v = rnd((R, Tk, H, S), 62)
+  if spike:
+    k[0, Tk - 3, 0] = q[0, 5, 0] * 6.0               # one key that dominates query 5 in the LAST tile
+  if big_offset:
+    k = k + big_offset * q.mean(dim=1, keepdim=True) / 8.0
+  scale = S ** -0.5
+  qb, kb, vb = q.to(BF), k.to(BF), v.to(BF)
+  logits = torch.einsum("nqhs,nchs->nhqc", qb.float(), kb.float()) * scale
+  ref = torch.einsum("nhqc,nchs->nqhs", torch.softmax(logits, dim=3), vb.float())
+  # what the projections deliver: q in the exp2 domain, 1.0 in dim 40 of k and in row 40 of V^T
+  qd = torch.zeros(R, Tq, H, sp)
+  qd[..., :S] = qb.float() * (scale * L.MS_LOG2E)
+  kd = torch.zeros(R, Tk, H, sp)
+  kd[..., :S] = kb.float()
+  kd[..., L.MS_DIM] = 1.0
+  tkp = (Tk + 7) // 8 * 8 + 8
+  vt = torch.full((R, H * sp, tkp), float("nan"))
+  vv = torch.zeros(R, Tk, H, sp)
+  vv[..., :S] = vb.float()
+  vv[..., L.MS_DIM] = 1.0
+  vt[:, :, :Tk] = vv.reshape(R, Tk, H * sp).permute(0, 2, 1)
+  out = torch.full((R, Tq, H * sp), float("nan"), dtype=BF, device=dev)
+  o.attention(qd.reshape(R, Tq, H * sp).to(BF).to(dev), kd.reshape(R, Tk, H * sp).to(BF).to(dev),
+              vt.to(BF).to(dev), out, H, sp, scale, matrix_softmax=True)
+  got = out.reshape(R, Tq, H, sp).float().cpu()
+  assert float(got[..., S:].abs().max()) == 0.0       # the padded output dims (incl. the denominator's) are zero
+  # the plain kernel on the same bf16 q / k / v
+  out0 = torch.empty(R, Tq, H * sp, dtype=BF, device=dev)
+  q0 = torch.zeros(R, Tq, H, sp); q0[..., :S] = qb.float()
+  k0 = torch.zeros(R, Tk, H, sp); k0[..., :S] = kb.float()
+  vt0 = torch.zeros(R, H * sp, tkp)
+  v0 = torch.zeros(R, Tk, H, sp); v0[..., :S] = vb.float()
+  vt0[:, :, :Tk] = v0.reshape(R, Tk, H * sp).permute(0, 2, 1)
+  o.attention(q0.reshape(R, Tq, H * sp).to(BF).to(dev), k0.reshape(R, Tk, H * sp).to(BF).to(dev), vt0.to(BF).to(dev),
+              out0, H, sp, scale)
+  r, r0 = rel(got[..., :S], ref), rel(out0.reshape(R, Tq, H, sp)[..., :S], ref)
+  print(f"attention_ms R={R} H={H} Tq={Tq} Tk={Tk} spike={spike} offset={big_offset}: rel {r:.3e} (plain kernel {r0:.3e})")
+  # q is rounded once more (after the exp2-domain scale): a little above the plain kernel's bf16 error
+  assert r < 8e-3 and r < 2.5 * r0 + 1e-3
+
+
+@pytest.mark.parametrize("R,H,Tq,Tk", [(2, 8, 256, 256), (2, 8, 192, 77), (1, 4, 1024, 1024), (1, 2, 100, 130)])
+def test_attention_matrix_softmax(dev, R, H, Tq, Tk):
+  _ms_case(dev, R, H, Tq, Tk)
+
+
+def test_attention_matrix_softmax_reference_moves(dev):
+  """a dominating key in the last tile forces the reference to move late; a large common offset makes the
+  first tile's maximum far from 0 in either direction"""
+  _ms_case(dev, 1, 2, 256, 256, spike=True)
+  _ms_case(dev, 1, 2, 128, 200, big_offset=40.0)
+  _ms_case(dev, 1, 2, 128, 200, big_offset=-40.0)

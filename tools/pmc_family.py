@@ -40,7 +40,10 @@ for path in args:
              "dur": collections.defaultdict(float), "cnt": collections.defaultdict(int), "seen": set()}
     if win is None:
       continue
+    # gn_fused_kernel<..., true> = ldm_groupnorm_splitk: the split-K reduce of a conv fused into the
+    # GroupNorm that consumes it -- counted with the GEMM family (it reads that family's f32 slabs)
     f = ("gemm_kernel" if ("gemm_kernel<" in n or "gemm3_kernel<" in n) else "attn_kernel" if "attn_kernel" in n else
+         "groupnorm_splitk" if ("gn_fused_kernel<" in n and ", true>" in n) else
          "groupnorm" if "gn_" in n else "layernorm" if "layernorm" in n else
          "splitk_reduce" if "splitk" in n else "other")
     win["fam"][f][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -71,13 +74,15 @@ if out_json:
   # the family bench.py's roofline names = every launch ldm_gemm makes: the GEMM / conv kernels AND
   # their split-K reduce launches
   g = dict(totals.get("gemm_kernel", {}))
-  for c, v in totals.get("splitk_reduce", {}).items():
-    g[c] = g.get(c, 0.0) + v
+  for extra in ("splitk_reduce", "groupnorm_splitk"):
+    for c, v in totals.get(extra, {}).items():
+      g[c] = g.get(c, 0.0) + v
   res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; "
-                   "family = gemm_kernel<...> + gemm3_kernel<...> + splitk_epilogue*; per U-Net evaluation (dispatches between time_embedding_kernel and cfg_ddim_kernel only)",
+                   "family = gemm_kernel<...> + gemm3_kernel<...> + splitk_epilogue* + the GroupNorm launches that complete a deferred split-K product (gn_fused_kernel<..., true>: their own GroupNorm read/write is included, an over-count); per U-Net evaluation (dispatches between time_embedding_kernel and cfg_ddim_kernel only)",
          "fetch_kb_raw_per_eval": g.get("FETCH_SIZE"), "write_kb_raw_per_eval": g.get("WRITE_SIZE"),
          "launches_per_eval": (totals.get("_launches_per_eval", {}).get("gemm_kernel", 0) +
-                               totals.get("_launches_per_eval", {}).get("splitk_reduce", 0))}
+                               totals.get("_launches_per_eval", {}).get("splitk_reduce", 0) +
+                               totals.get("_launches_per_eval", {}).get("groupnorm_splitk", 0))}
   if g.get("FETCH_SIZE") is not None and g.get("WRITE_SIZE") is not None:
     res["hbm_read_bytes_per_eval"] = g["FETCH_SIZE"] * 1024.0 * 2.0     # gfx950 correction
     res["hbm_write_bytes_per_eval"] = g["WRITE_SIZE"] * 1024.0

@@ -28,7 +28,8 @@ def main():
   tot = sum(float(r["TotalDurationNs"]) for r in rows)
   evals = sum(int(r["Calls"]) for r in rows if "time_embedding_kernel" in r["Name"])
   gemm = [r for r in rows if "gemm_kernel<" in r["Name"] or "gemm3_kernel<" in r["Name"]]
-  red = [r for r in rows if "splitk_epilogue" in r["Name"]]
+  # split-K reduces: the plain reduce launches and the GroupNorm launches that complete a deferred product
+  red = [r for r in rows if "splitk_epilogue" in r["Name"] or ("gn_fused_kernel<" in r["Name"] and ", true>" in r["Name"])]
   red_ns = sum(float(r["TotalDurationNs"]) for r in red)
   gemm_ns = sum(float(r["TotalDurationNs"]) for r in gemm)
   gemm_calls = sum(int(r["Calls"]) for r in gemm)
@@ -41,7 +42,7 @@ def main():
           f"(incl. the text encoder's and decoder's launches, which add a few %), "
           f"average launch {gemm_ns / 1e3 / max(gemm_calls, 1):.1f} us")
     print(f"* the family as bench.py's `roofline` defines it (every launch made by `ldm_gemm`: `gemm_kernel<...>` "
-          f"+ its split-K reduce `splitk_epilogue*`): **{(gemm_ns + red_ns) / 1e6 / evals:.3f} ms per U-Net evaluation**, "
+          f"+ its split-K reduce `splitk_epilogue*` / `gn_fused_kernel<..., true>` = reduce fused with the next GroupNorm): **{(gemm_ns + red_ns) / 1e6 / evals:.3f} ms per U-Net evaluation**, "
           f"{(gemm_calls + sum(int(r['Calls']) for r in red)) / evals:.0f} kernel launches per evaluation")
     print(f"* all kernels: {tot / 1e6 / evals:.3f} ms per U-Net evaluation (upper bound: includes text encoder + decoder)")
   if args.bench_json:

@@ -36,6 +36,8 @@ def main():
   ap.add_argument("--keep-plans", action="store_true", help="start from the loaded plan table (refinement pass)")
   ap.add_argument("--tiles", default="", help="only candidates on these tiles (comma list), e.g. a refinement pass for new tiles")
   ap.add_argument("--max-m", type=int, default=0, help="only problems with M <= this")
+  ap.add_argument("--start-index", type=int, default=0,
+                  help="skip the first problems of the (largest first) order: continue an earlier pass that ran out of budget")
   args = ap.parse_args()
   dev = torch.device("cuda:0")
   dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -92,10 +94,13 @@ def main():
   plans, cur = {k: list(v) for k, v in ops.gemm_plans().items() if k in keys}, base
   # biggest problems first (they carry the most time)
   order = sorted(keys.items(), key=lambda kv: -(kv[1][0] * kv[1][1] * kv[1][2] * kv[1][3]))
-  for key, (M, N, K, batch, act, dtype) in order:
+  for pi, (key, (M, N, K, batch, act, dtype)) in enumerate(order):
+    if pi < args.start_index:
+      continue
     if time.time() - t_start > args.budget_s:
-      print("time budget reached", flush=True)
+      print(f"time budget reached at problem {pi} of {len(order)}", flush=True)
       break
+    print(f"[{pi}] {key}", flush=True)
     if args.max_m and M > args.max_m:
       continue
     start = ops.gemm_plans().get(key)
@@ -104,7 +109,7 @@ def main():
     for cand in ops.plan_candidates(M, N, K, batch, act, dtype, key=key):
       if only is not None and cand[0] not in only:
         continue
-      if key.endswith(" t1") and cand[0] not in (13, 14):     # whole-product-transposed launches: persistent kernel only
+      if (" t1" in key or " ln1" in key) and cand[0] not in (13, 14):   # transposed / LayerNorm-fold launches: persistent kernel only
         continue
       ops.set_plan(key, cand)
       try:
