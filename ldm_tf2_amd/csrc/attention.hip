@@ -16,6 +16,7 @@
 // flight during the current tile's MFMAs.  Logits are never written to memory.
 #include "common.h"
 #include <atomic>
+#include <stdlib.h>
 
 namespace {
 
@@ -96,11 +97,19 @@ template <> struct AttnTraits<float> {
 // fragment in registers; the reference only moves when some query's tile maximum exceeds it by 2^8
 // (as before), and then by an amount that keeps it a bf16 number, so numerator and denominator see
 // exactly the same reference.
-template <typename T, int SP, int KT, bool MS = false>
+// NWV / PF: waves per workgroup (4 or 8: 128 or 256 queries share one K / V^T tile) and the prefetch
+// distance of the register-staged tiles (1 or 2).  The 4-wave form keeps ONE tile in flight while one is
+// multiplied: at d = 40 a tile is ~0.5 us of work per workgroup against 1-2 us of memory latency under
+// load, and the four resident workgroups of a CU all wait the same way (the kernel ran 3x above its
+// MFMA / VALU bound).  With 8 waves a tile costs each thread half the staging registers, so TWO tiles
+// fit in flight within the same register budget.
+template <typename T, int SP, int KT, bool MS = false, int NWV = 4, int PF = 1>
 // Waves per SIMD: the softmax (VALU, exp2) and the two MFMA phases of different waves overlap,
 // so residency pays: measured 130 -> 109 -> 91 us at T = 1024, Sp = 48 for 2 -> 3 -> 4 waves per
 // SIMD (5 spills 144 bytes per lane and loses again); the wide heads keep the compiler's choice.
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4 : 1) : 1)) void attn_kernel(AttnArgs p) {
+__global__ __launch_bounds__(64 * NWV, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4 : 1) : 1)) void attn_kernel(AttnArgs p) {
+  constexpr int NT = 64 * NWV;
+  static_assert((NWV == 4 || NWV == 8) && (PF == 1 || PF == 2), "attention workgroup shape");
   using TR = AttnTraits<T>;
   constexpr int EPC = Elem<T>::kPerChunk;
   constexpr int NPC = TR::NPC;
@@ -111,8 +120,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
   constexpr int ND = (SP + 31) / 32;            // O^T tiles
   constexpr int KRS = SP * (int)sizeof(T) + 16; // padded LDS row strides (odd * 16 B)
   constexpr int VRS = KT * (int)sizeof(T) + 16;
-  constexpr int CK = (KT * DCH + 255) / 256;
-  constexpr int CV = (SP * VCH + 255) / 256;
+  constexpr int CK = (KT * DCH + NT - 1) / NT;
+  constexpr int CV = (SP * VCH + NT - 1) / NT;
   static_assert(SP % 16 == 0 && KT % 32 == 0 && (SP * (int)sizeof(T)) % 32 == 0, "attention tile");
 
   __shared__ __attribute__((aligned(16))) char smem[KT * KRS + ND * 32 * VRS];
@@ -122,7 +131,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int head = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = blockIdx.x * (32 * NWV) + wave * 32;
 
   const T* Q = (const T*)p.q + (int64_t)b * p.q_bs + (int64_t)head * SP;
   const T* Kp = (const T*)p.k + (int64_t)b * p.k_bs + (int64_t)head * SP;
@@ -147,11 +156,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
   float m_run = MS ? 0.f : -INFINITY, l_run = 0.f;   // running max (log2 domain) and sum; MS: Q[RD] = -0 initially
   const float c2 = p.scale * 1.4426950408889634f;  // scale * log2(e)
 
-  u32x4 rk[CK], rv[CV];
-  auto load_tile = [&](int kt0) {
+  u32x4 rkA[CK], rvA[CV];
+  [[maybe_unused]] u32x4 rkB[PF == 2 ? CK : 1], rvB[PF == 2 ? CV : 1];   // second tile in flight (PF = 2)
+  auto load_tile = [&](int kt0, u32x4 (&rk)[CK], u32x4 (&rv)[CV]) {
 #pragma unroll
     for (int i = 0; i < CK; ++i) {
-      const int id = tid + i * 256;
+      const int id = tid + i * NT;
       const int key = id / DCH, dc = id - key * DCH;
       u32x4 v = {0u, 0u, 0u, 0u};
       if (id < KT * DCH && kt0 + key < p.Tk)
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
     }
 #pragma unroll
     for (int i = 0; i < CV; ++i) {
-      const int id = tid + i * 256;
+      const int id = tid + i * NT;
       const int dim = id / VCH, kc = id - dim * VCH;
       u32x4 v = {0u, 0u, 0u, 0u};
       const int left = p.Tk - (kt0 + kc * EPC);        // keys of this chunk that exist
@@ -171,16 +181,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
       rv[i] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](const u32x4 (&rk)[CK], const u32x4 (&rv)[CV]) {
 #pragma unroll
     for (int i = 0; i < CK; ++i) {
-      const int id = tid + i * 256;
+      const int id = tid + i * NT;
       const int key = id / DCH, dc = id - key * DCH;
       if (id < KT * DCH) *(u32x4*)(sK + key * KRS + dc * 16) = rk[i];
     }
 #pragma unroll
     for (int i = 0; i < CV; ++i) {
-      const int id = tid + i * 256;
+      const int id = tid + i * NT;
       const int dim = id / VCH, kc = id - dim * VCH;
       if (id < SP * VCH) *(u32x4*)(sV + dim * VRS + kc * 16) = rv[i];
     }
@@ -188,13 +198,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
 
   const int krow = TR::kappa(lr);
   const int ntiles = (p.Tk + KT - 1) / KT;
-  load_tile(0);
-  for (int t = 0; t < ntiles; ++t) {
+  // one staged tile in LDS -> S^T, softmax, O^T update
+  auto tile_body = [&](int t) {
     const int kt0 = t * KT;
-    __syncthreads();
-    store_tile();
-    __syncthreads();
-    if (t + 1 < ntiles) load_tile(kt0 + KT);
 
     // ---- S^T = K . Q^T ---------------------------------------------------------
     f32x16 s[NSUB];
@@ -303,6 +309,33 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 64 ? 4
           mma32a(o[d], vf, pf, T());
         }
       }
+  };
+
+  load_tile(0, rkA, rvA);
+  if constexpr (PF == 2) {
+    if (ntiles > 1) load_tile(KT, rkB, rvB);
+    for (int t = 0; t < ntiles; t += 2) {
+      __syncthreads();
+      store_tile(rkA, rvA);
+      __syncthreads();
+      if (t + 2 < ntiles) load_tile((t + 2) * KT, rkA, rvA);
+      tile_body(t);
+      if (t + 1 < ntiles) {                           // (uniform)
+        __syncthreads();
+        store_tile(rkB, rvB);
+        __syncthreads();
+        if (t + 3 < ntiles) load_tile((t + 3) * KT, rkB, rvB);
+        tile_body(t + 1);
+      }
+    }
+  } else {
+    for (int t = 0; t < ntiles; ++t) {
+      __syncthreads();
+      store_tile(rkA, rvA);
+      __syncthreads();
+      if (t + 1 < ntiles) load_tile((t + 1) * KT, rkA, rvA);
+      tile_body(t);
+    }
   }
 
   float l_tot;
@@ -521,6 +554,16 @@ __global__ __launch_bounds__(256) void attn_wide_kernel(AttnArgs p) {
   }
 }
 
+// A/B of the workgroup shape (tools build only: the product library reads no environment variable)
+static bool force_4_waves() {
+#ifdef LDM_TOOLS_BUILD
+  static const bool f = getenv("LDM_ATTN_WAVES") && atoi(getenv("LDM_ATTN_WAVES")) == 4;
+  return f;
+#else
+  return false;
+#endif
+}
+
 template <typename T>
 int launch_attn_wide(const AttnArgs& a, int batch, hipStream_t s) {
   constexpr int ES = (int)sizeof(T);
@@ -550,6 +593,14 @@ int launch_attn(const AttnArgs& a, int Sp, dim3 grid, hipStream_t s) {
   case SPV:                                                                                      \
     hipLaunchKernelGGL((attn_kernel<T, SPV, H ? KTB : KTF>), grid, dim3(256), 0, s, a);          \
     break;
+  if constexpr (H) {
+    // 40-wide heads with long query runs: 8-wave workgroups, two staged tiles in flight (NWV = 8, PF = 2)
+    if (Sp == 48 && a.Tq >= 256 && !force_4_waves()) {
+      dim3 g8((a.Tq + 255) / 256, grid.y, grid.z);
+      hipLaunchKernelGGL((attn_kernel<T, 48, 64, false, 8, 2>), g8, dim3(512), 0, s, a);
+      return 0;
+    }
+  }
   switch (Sp) {
     ATTN_CASE(32, 128, 64)
     ATTN_CASE(48, 64, 32)
@@ -580,8 +631,13 @@ extern "C" int ldm_attention_ms(const void* q, int64_t ldq, int64_t q_bs, const 
   a.q = (const char*)q; a.k = (const char*)k; a.vt = (const char*)vt; a.out = (char*)out;
   a.ldq = ldq; a.q_bs = q_bs; a.ldk = ldk; a.k_bs = k_bs; a.ldvt = ldvt; a.vt_bs = vt_bs;
   a.ldo = ldo; a.o_bs = o_bs; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.scale = 1.0f;
-  dim3 grid((Tq + 127) / 128, heads, batch);
-  hipLaunchKernelGGL((attn_kernel<bf16_t, 48, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  if (Tq >= 256 && !force_4_waves()) {      // long query runs: 8-wave workgroups, two staged tiles in flight
+    dim3 g8((Tq + 255) / 256, heads, batch);
+    hipLaunchKernelGGL((attn_kernel<bf16_t, 48, 64, true, 8, 2>), g8, dim3(512), 0, (hipStream_t)stream, a);
+  } else {
+    dim3 grid((Tq + 127) / 128, heads, batch);
+    hipLaunchKernelGGL((attn_kernel<bf16_t, 48, 64, true>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   return ldm_launch_status("ldm_attention_ms");
 }
 

@@ -315,6 +315,8 @@ def _attn_case(dev, dtype, R, H, S, Tq, Tk, sp):
     dict(R=2, H=8, S=40, Tq=256, Tk=256, sp=48),     # head sizes the U-Net uses: 40->48, 80->80
     dict(R=2, H=8, S=40, Tq=192, Tk=77, sp=48),
     dict(R=1, H=8, S=80, Tq=64, Tk=200, sp=80),
+    dict(R=1, H=4, S=40, Tq=1000, Tk=333, sp=48),    # 8-wave workgroups (Tq >= 256), ragged queries and keys, 6 tiles
+    dict(R=1, H=2, S=40, Tq=256, Tk=64, sp=48),      # 8-wave workgroups, ONE tile
 ])
 def test_attention(dev, dtype, case):
   _attn_case(dev, dtype, **case)

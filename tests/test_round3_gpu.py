@@ -260,7 +260,8 @@ def _ms_case(dev, R, H, Tq, Tk, spike=False, big_offset=0.0):
   assert r < 8e-3 and r < 2.5 * r0 + 1e-3
 
 
-@pytest.mark.parametrize("R,H,Tq,Tk", [(2, 8, 256, 256), (2, 8, 192, 77), (1, 4, 1024, 1024), (1, 2, 100, 130)])
+@pytest.mark.parametrize("R,H,Tq,Tk", [(2, 8, 256, 256), (2, 8, 192, 77), (1, 4, 1024, 1024), (1, 2, 100, 130),
+                                       (1, 2, 1000, 333), (1, 2, 300, 64), (1, 2, 512, 77)])
 def test_attention_matrix_softmax(dev, R, H, Tq, Tk):
   _ms_case(dev, R, H, Tq, Tk)
 
