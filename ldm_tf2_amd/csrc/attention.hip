@@ -102,7 +102,14 @@ template <> struct AttnTraits<float> {
 // multiplied: at d = 40 a tile is ~0.5 us of work per workgroup against 1-2 us of memory latency under
 // load, and the four resident workgroups of a CU all wait the same way (the kernel ran 3x above its
 // MFMA / VALU bound).  With 8 waves a tile costs each thread half the staging registers, so TWO tiles
-// fit in flight within the same register budget.
+// fit in flight within the same register budget (T = 1024, d = 40, same box: 115 -> 110 us plain, 97 -> 86 us
+// with the matrix-side softmax).  A ping-ponged form on top of it -- the late half of the 8 waves defers
+// O += V^T P by one barrier period (P kept in registers, three tile buffers in LDS, one barrier per tile) so
+// that one wave's softmax runs beside its SIMD partner's MFMAs -- was built, passed every parity test and
+// measured SLOWER (90.8 vs 84.4 us): removed again.  The PMC anatomy (tools/attn_pmc_probe.py,
+// profiles/r03_probes.txt) shows the waves parked at waits 45 % of their cycles with the matrix pipe 31 %
+// busy: the dependent chain LDS read -> MFMA -> exp2 -> pack -> LDS read -> MFMA inside one wave is what a
+// tile costs, whatever the partner does.
 template <typename T, int SP, int KT, bool MS = false, int NWV = 4, int PF = 1>
 // Waves per SIMD: the softmax (VALU, exp2) and the two MFMA phases of different waves overlap,
 // so residency pays: measured 130 -> 109 -> 91 us at T = 1024, Sp = 48 for 2 -> 3 -> 4 waves per
@@ -376,6 +383,7 @@ __global__ __launch_bounds__(64 * NWV, (sizeof(T) == 2 ? (SP == 32 ? 3 : SP <= 6
 }
 
 
+
 // ---- wide heads (SP = 512: the autoencoder's single-head attention, autoencoder.py:74-97) ----------
 // A lane-owned O^T column of 512 dims would need 256 accumulator registers, so the head dim is
 // SPLIT over the 4 waves of a workgroup: all four waves serve the SAME 32 queries, wave w owns dims
@@ -631,7 +639,7 @@ extern "C" int ldm_attention_ms(const void* q, int64_t ldq, int64_t q_bs, const 
   a.q = (const char*)q; a.k = (const char*)k; a.vt = (const char*)vt; a.out = (char*)out;
   a.ldq = ldq; a.q_bs = q_bs; a.ldk = ldk; a.k_bs = k_bs; a.ldvt = ldvt; a.vt_bs = vt_bs;
   a.ldo = ldo; a.o_bs = o_bs; a.heads = heads; a.Tq = Tq; a.Tk = Tk; a.scale = 1.0f;
-  if (Tq >= 256 && !force_4_waves()) {      // long query runs: 8-wave workgroups, two staged tiles in flight
+  if (Tq >= 256 && !force_4_waves()) {      // long query runs: 8-wave workgroups
     dim3 g8((Tq + 255) / 256, heads, batch);
     hipLaunchKernelGGL((attn_kernel<bf16_t, 48, 64, true, 8, 2>), g8, dim3(512), 0, (hipStream_t)stream, a);
   } else {
