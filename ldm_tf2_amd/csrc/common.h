@@ -109,8 +109,22 @@ __device__ __forceinline__ float erf_as_f(float x) {
   const float r = 1.0f - poly * t * e;
   return copysignf(r, x);
 }
+// 0.5 x (1 + erf(x / sqrt 2)) with the same A&S erf, rearranged so that the sign handling and the
+// "1 -" disappear: erf(z) = sign (1 - q), q = poly(t) t exp(-z^2)  =>  gelu(x) = max(x, 0) - 0.5 |x| q.
+// 13 full-rate + 2 transcendental VALU operations instead of 17 + 2 (the GEGLU epilogue of the persistent
+// kernel is exposed VALU time); same approximation error (1.5e-7), no cancellation on either side of 0.
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erf_as_f(x * 0.70710678118654752440f));
+  const float ax = fabsf(x);
+  const float z = ax * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+  float poly = 1.061405429f;
+  poly = __builtin_fmaf(poly, t, -1.453152027f);
+  poly = __builtin_fmaf(poly, t, 1.421413741f);
+  poly = __builtin_fmaf(poly, t, -0.284496736f);
+  poly = __builtin_fmaf(poly, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);
+  const float q = poly * t * e;                       // 1 - erf(z), in [0, 1]
+  return __builtin_fmaf(-0.5f * ax, q, fmaxf(x, 0.f));
 }
 
 // ---- wave reductions (wave = 64) ------------------------------------------

@@ -377,7 +377,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
             for (int h = 0; h < 2; ++h)
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                acc[ip + h][j][r] = rrs[h][r] * (acc[ip + h][j][r] - rmu[h][r] * cs) + bb;
+                acc[ip + h][j][r] = __builtin_fmaf(rrs[h][r], acc[ip + h][j][r], __builtin_fmaf(-rrs[h][r] * rmu[h][r], cs, bb));
           }
           const uint32_t x0 = pack_bf2(acc[ip][j][0], acc[ip][j][1]), x1 = pack_bf2(acc[ip][j][2], acc[ip][j][3]);
           const uint32_t y0 = pack_bf2(acc[ip + 1][j][0], acc[ip + 1][j][1]), y1 = pack_bf2(acc[ip + 1][j][2], acc[ip + 1][j][3]);
@@ -425,19 +425,21 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
         for (int j = 0; j < NOB; ++j) rv[j] = *(const u32x2*)(rr + 16 * j);
       }
       [[maybe_unused]] float mu_i = 0.f, rs_i = 0.f;         // statistics of row 16 i + lr: held by that lane
+      [[maybe_unused]] float nm_i = 0.f;                       // -rstd * mean
       if constexpr (LN) {
         mu_i = __shfl(ln_mu, 16 * i + lr, 64);
         rs_i = __shfl(ln_r, 16 * i + lr, 64);
+        nm_i = -rs_i * mu_i;
       }
       // value of block j, registers r = 0..3 (columns n_w + 16 j + 4 g + r), before the residual
       auto block = [&](int j, float (&v)[4]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
         if constexpr (LN) {
+          // rstd (acc - mean cs) + b' as two fmas: rstd acc + (b' - rstd mean cs)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = rs_i * (v[r] - mu_i * csv[j][r]);
-        }
-        if constexpr (HB) {
+          for (int r = 0; r < 4; ++r) v[r] = __builtin_fmaf(rs_i, v[r], __builtin_fmaf(nm_i, csv[j][r], bv[j][r]));
+        } else if constexpr (HB) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += bv[j][r];
         }
