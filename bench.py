@@ -375,7 +375,9 @@ def main():
                 "frac": achieved / peak, "traffic": traffic,
                 "traffic_unit": ("HBM bytes per U-Net step for this kernel family, from the committed PMC passes of the same "
                                  f"workload (profiles/{os.path.basename(tj) if tj else '-'}; tools/profile_round.sh reproduces them)"),
-                "kernel": "every launch of ldm_gemm: gemm_kernel<T,BM,BN,WM,WN,MODE,MF,ST> + gemm3_kernel<TN,MODE,EPI> (Dense/1x1/projection GEMMs + implicit-GEMM 3x3 convs) + their split-K reduce",
+                "kernel": ("every launch of ldm_gemm: gemm_kernel<T,BM,BN,WM,WN,MODE,MF,ST,NS> + gemm3_kernel<TN,MODE,EPI> (Dense/1x1/"
+                           "projection GEMMs incl. the LayerNorm-folded ones + implicit-GEMM 3x3 convs) + their split-K reduces (plain "
+                           "launches, and the extra time of the GroupNorm launches that complete a deferred reduce)"),
                 "launches_per_unet_step": n_launches, "ms_per_unet_step_in_kernel": gemm_ms,
                 "avg_launch_us": gemm_ms * 1e3 / max(n_launches, 1),
                 "ms_unet_step_graph_full": t_full, "ms_unet_step_graph_without_family": t_rest,
