@@ -276,6 +276,21 @@ int ldm_attention_ms(const void* q, int64_t ldq, int64_t q_bs, const void* k, in
                      int64_t ldo, int64_t o_bs, int batch, int heads, int Tq, int Tk, int Sp,
                      int dtype, void* stream);
 
+/*
+ * Fused feed-forward of the BasicTransformerBlock (unet.py:313, :323-325, :335-338) for bf16 rows of C = 320:
+ *     out[m] = x[m] + b2 + W2 . ( a * gelu(g) ),   (a | g) = W1 . LayerNorm(x[m]) + b1
+ * as ONE launch per 128-row panel: the panel's input rows stay resident in LDS (A operand of all hidden
+ * chunks, source of the LayerNorm statistics, residual), the [M, 4C] hidden activation never leaves the CU,
+ * only weights stream.  x: [M][C] bf16 (row stride ldx); w1: [8C][C] bf16, gamma-folded and
+ * GEGLU-interleaved (layout.ln_fold of layout.geglu_kernel); aux: float32 [8C / 128][256]: per 128 rows of
+ * w1 their column sums (128) then their folded bias (128); w2: [C][4C] bf16; b2: [C]; out: [M][C] bf16.
+ * Same arithmetic as ldm_gemm(ln_cs, GEGLU) followed by ldm_gemm(residual) except that the hidden
+ * activation is rounded to bf16 in LDS instead of HBM (identical rounding points).
+ */
+int ldm_ffn_geglu_supported(int M, int C, int dtype);
+int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const float* aux, const void* w2,
+                  const float* b2, void* out, int64_t ldo, int M, int C, float eps, int dtype, void* stream);
+
 /* Sinusoidal timestep embedding, cos first (unet.py:401-422): out[r][0:half]=cos(t*f),
  * out[r][half:]=sin(t*f), f_k = exp(-ln(10000)*k/half), float32.  t is read from
  * steps[*index] when `index` != NULL (device-resident DDIM index, graph replay) else

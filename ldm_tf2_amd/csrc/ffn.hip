@@ -1,0 +1,338 @@
+// Fused feed-forward of the BasicTransformerBlock for the 320-channel level (unet.py:313, :323-325, :335-338):
+//
+//     out = x + Dense_{4C->C}( a * gelu(g) ) + b2,   (a | g) = Dense_{C->8C}( LayerNorm(x) ) + b1
+//
+// as ONE launch per 128-row panel of the residual stream (bf16, C = 320), instead of LayerNorm ->
+// GEGLU GEMM -> [M, 4C] in HBM -> FF-out GEMM.  The design is a row-panel kernel, not a per-layer GEMM:
+//   * the panel's 128 x 320 input rows are staged ONCE (LDS-DMA, 80 KB, the GEMM kernels' swizzled K-tile
+//     image) and stay resident: they are the A operand of all 20 hidden chunks, the source of the
+//     LayerNorm statistics (the LayerNorm is folded into the first Dense as in gemm3_kernel.h, EPI bit 6)
+//     and never re-staged -- the persistent GEMM re-stages its A K-tiles for every n-tile, 2/3 of its
+//     LDS-DMA traffic;
+//   * the hidden activation never leaves the CU: per chunk of 64 hidden units the first product
+//     (128 x 128: 64 value + 64 gate columns, K = 320) is finished in registers, GEGLU'd, rounded to bf16
+//     and written into a 16 KB LDS tile that is exactly one A K-tile of the second product;
+//   * the second product accumulates out[128 x 320] in registers over the 20 chunks (three 128-column
+//     pieces, 96 accumulator registers per lane) and gets bias + residual in the final epilogue;
+//   * only weights stream: one 16 KB tile (128 weight rows x 64 K) per barrier period through a 3-stage
+//     ring, 8 periods per chunk (5 K-tiles of W1, 3 column pieces of W2); the chunk's folded bias /
+//     column sums ride in the ring as one extra 1 KB LDS-DMA, so the loop contains no ordinary global
+//     load (those would drain the DMA queue at their first use).
+// Work per workgroup: 160 barrier periods of 16 MFMAs (16x16x32) per wave; 256 workgroups for M = 32768.
+#include "common.h"
+
+namespace {
+
+struct FfnArgs {
+  const char* x;       // [M][C] bf16, row stride ldx elements: LayerNorm input AND residual
+  const char* w1;      // [8C][C] bf16: gamma-folded, GEGLU-interleaved (blocks of 64 rows = 32 value + 32 gate)
+  const char* aux;     // [8C / 128][256] f32: per 128 weight rows of w1: column sums (128) | folded bias (128)
+  const char* w2;      // [C][4C] bf16
+  const float* b2;     // [C]
+  char* out;           // [M][C] bf16, row stride ldo
+  int64_t ldx, ldo;
+  uint32_t x_bytes, w1_bytes, w2_bytes, aux_bytes;
+  int M;
+  float eps;
+};
+
+constexpr uint32_t kOOBf = 0x80000000u;
+
+template <int C>
+__global__ __launch_bounds__(512) void ffn_geglu_kernel(FfnArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 128, NW = 8;
+  constexpr int KT1 = C / 64;                  // K-tiles of the first product (5)
+  constexpr int HID = 4 * C, NCH = HID / 64;   // hidden width, chunks of 64 hidden units (20)
+  constexpr int NP2 = (C + 127) / 128;         // 128-column pieces of the second product (3)
+  constexpr int SPC = KT1 + NP2;               // barrier periods per chunk (8)
+  constexpr int S = NCH * SPC;
+  constexpr int TILE = 128 * 128;              // one staged tile: 128 rows x 128 bytes
+  constexpr int STG = TILE + 1024;             // ring stage: weight tile + the chunk's (colsum | bias) KB
+  constexpr int NSTAGE = 3;
+  constexpr int OFF_H = KT1 * TILE, OFF_R = OFF_H + TILE;
+  static_assert(C % 64 == 0 && OFF_R + NSTAGE * STG <= 160 * 1024, "LDS");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  __shared__ __attribute__((aligned(16))) char smem[OFF_R + NSTAGE * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows 32 wm .. +31, columns 64 wn .. +63 of a 128 x 128 tile
+  const int lr = lane & 15, lh = lane >> 4;
+  const int m0 = blockIdx.x * BM;
+
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, p.w1_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, p.w2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.aux), 0, p.aux_bytes, 0x00020000);
+
+  // ---- staging geometry: a tile is 16 LDS-DMA instructions of 8 rows; wave w issues instructions w and w + 8.
+  // lane l lands at row 8 i + (l >> 3), 16-byte slot l & 7, and fetches chunk (l & 7) ^ ((row >> 1) & 7).
+  int srow[2], sck[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    srow[h] = (wave + 8 * h) * 8 + (lane >> 3);
+    sck[h] = ((lane & 7) ^ ((srow[h] >> 1) & 7)) * 16;
+  }
+  // resident input panel: KT1 tiles
+  {
+    uint32_t xo[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = m0 + srow[h];
+      xo[h] = m < p.M ? (uint32_t)((int64_t)m * p.ldx * 2) + sck[h] : kOOBf;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(smem + kt * TILE + (wave + 8 * h) * 1024), 16,
+                                                 xo[h] == kOOBf ? kOOBf : xo[h] + kt * 128, 0, 0, 0);
+  }
+  // weight tile of step s = (chunk c, period u) into ring slot `slot`; returns the DMAs this wave issued
+  auto issue = [&](int s, int slot) {
+    const int c = s / SPC, u = s - c * SPC;
+    char* dst = smem + OFF_R + slot * STG;
+    if (u < KT1) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t off = (uint32_t)((128 * c + srow[h]) * (C * 2) + u * 128 + sck[h]);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (lds_ptr)(dst + (wave + 8 * h) * 1024), 16, off, 0, 0, 0);
+      }
+      if (u == KT1 - 1)     // the chunk's (column sums | folded bias): 1 KB, every wave writes the same bytes
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsAux, (lds_ptr)(dst + TILE), 16, (uint32_t)(c * 1024 + lane * 16), 0, 0, 0);
+    } else {
+      const int pp = u - KT1;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int n = 128 * pp + srow[h];
+        const uint32_t off = n < C ? (uint32_t)(n * (HID * 2) + c * 128 + sck[h]) : kOOBf;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW2, (lds_ptr)(dst + (wave + 8 * h) * 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+  auto n_issued = [&](int s) { return (s % SPC) == KT1 - 1 ? 3 : 2; };
+
+  issue(0, 0);
+  issue(1, 1);
+
+  // ---- LayerNorm statistics of this wave's 32 rows from the resident panel -------------------------
+  // the panel's 2 * KT1 DMAs of this wave are older than the two weight tiles just issued
+  if (n_issued(0) + n_issued(1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  float ln_mu, ln_rs;
+  {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    const bf2 one = __builtin_bit_cast(bf2, 0x3f803f80u);
+    const int row = 32 * wm + (lane & 31), half = lane >> 5;   // lanes l and l + 32 split the row's chunks
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < KT1; ++kt) {
+      const char* base = smem + kt * TILE + row * 128 + half * 64;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const u32x4 cc = *(const u32x4*)(base + (((j + (row >> 1)) & 3) << 4));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t w = cc[e];
+          const bf2 a = __builtin_bit_cast(bf2, w);
+          s1 = __builtin_amdgcn_fdot2_f32_bf16(a, one, s1, false);
+          s2 = __builtin_amdgcn_fdot2_f32_bf16(a, a, s2, false);
+        }
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    const float ik = 1.0f / (float)C;
+    ln_mu = s1 * ik;
+    ln_rs = rsqrtf(fmaxf(s2 * ik - ln_mu * ln_mu, 0.f) + p.eps);
+  }
+  // statistics of the rows this lane owns in the MFMA layout: row 16 i + lr of the wave tile
+  float rs_i[2], nm_i[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float mu = __shfl(ln_mu, 16 * i + lr, 64);
+    rs_i[i] = __shfl(ln_rs, 16 * i + lr, 64);
+    nm_i[i] = -rs_i[i] * mu;
+  }
+
+  // ---- fragment addresses ------------------------------------------------------------------------
+  int offA[2][2], offB[2][4];       // [k group][block]: byte offsets inside a 128 x 128-byte tile
+#pragma unroll
+  for (int kg = 0; kg < 2; ++kg) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 32 * wm + 16 * i + lr;
+      offA[kg][i] = row * 128 + (((kg * 4 + lh) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = 64 * wn + 16 * j + lr;
+      offB[kg][j] = row * 128 + (((kg * 4 + lh) ^ ((row >> 1) & 7)) << 4);
+    }
+  }
+
+  f32x4 acc1[2][4], acc2[NP2][2][4];
+#pragma unroll
+  for (int pp = 0; pp < NP2; ++pp)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc2[pp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // operands swapped (D = W_frag x A_frag): the lane owns row 16 i + lr and columns 16 j + 4 lh + r
+  // (one k group of fragments at a time: 6 fragments live instead of 12 -- the 96 + 32 accumulator
+  // registers leave no room for both)
+  // A fragments (resident panel / hidden tile) are read by read_a BEFORE the period's barrier where they do
+  // not depend on it (the panel never changes): their LDS latency then lies under the wait for the weights.
+  u32x4 fa[2][2];
+  auto read_a = [&](const char* sa) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[kg][i] = *(const u32x4*)(sa + offA[kg][i]);
+  };
+  auto mma_tile = [&](const char* sb, f32x4 (&acc)[2][4]) {
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      u32x4 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(sb + offB[kg][j]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]),
+                                                              __builtin_bit_cast(bf16x8, fa[kg][i]), acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // One barrier period per step s = (chunk c, period u).  The u loop is unrolled (the period's role, the
+  // accumulator piece and the DMA count are compile-time per instance); ring slot of step s = s % 3.
+  int slot = 0;
+  for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+    for (int u = 0; u < SPC; ++u) {
+      const int s = c * SPC + u;
+      if (u < KT1) read_a(smem + u * TILE);          // panel K-tile u: independent of the barrier below
+      // this wave's DMAs of step s have landed; those of step s + 1 may stay in flight
+      if (s + 1 < S) {
+        if (((u + 1) % SPC) == KT1 - 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (u == KT1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's writes of the hidden tile are in LDS
+      __builtin_amdgcn_s_barrier();
+      if (u >= KT1) read_a(smem + OFF_H);            // the hidden tile: visible after the barrier
+      const char* sb = smem + OFF_R + slot * STG;
+      {
+        int sn = slot + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+        if (s + 2 < S) issue(s + 2, sn);
+      }
+      {
+        if (u < KT1) {
+          if (u == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+          mma_tile(sb, acc1);
+          if (u == KT1 - 1) {
+            // GEGLU of the chunk: blocks 0, 1 = value, blocks 2, 3 = gate (one 64-row block of the interleaved
+            // weights per wave); LayerNorm fold: rstd acc + (b' - rstd mean cs); result -> bf16 -> hidden tile
+            const float* aux = (const float*)(sb + TILE);
+#pragma unroll
+            for (int jp = 0; jp < 2; ++jp) {
+              const f32x4 csv = *(const f32x4*)(aux + 64 * wn + 16 * jp + 4 * lh);
+              const f32x4 csg = *(const f32x4*)(aux + 64 * wn + 16 * (jp + 2) + 4 * lh);
+              const f32x4 bv = *(const f32x4*)(aux + 128 + 64 * wn + 16 * jp + 4 * lh);
+              const f32x4 bg = *(const f32x4*)(aux + 128 + 64 * wn + 16 * (jp + 2) + 4 * lh);
+#pragma unroll
+              for (int i = 0; i < 2; ++i) {
+                float hv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const float val = __builtin_fmaf(rs_i[i], acc1[i][jp][r], __builtin_fmaf(nm_i[i], csv[r], bv[r]));
+                  const float gat = __builtin_fmaf(rs_i[i], acc1[i][jp + 2][r], __builtin_fmaf(nm_i[i], csg[r], bg[r]));
+                  hv[r] = val * gelu_erf_f(gat);
+                }
+                u32x2 pk;
+                pk[0] = pack_bf2(hv[0], hv[1]);
+                pk[1] = pack_bf2(hv[2], hv[3]);
+                // hidden column (inside the chunk) 32 wn + 16 jp + 4 lh + r -> 16-byte chunk 4 wn + 2 jp + (lh >> 1)
+                const int row = 32 * wm + 16 * i + lr;
+                const int ck = (4 * wn + 2 * jp + (lh >> 1)) ^ ((row >> 1) & 7);
+                *(u32x2*)(smem + OFF_H + row * 128 + ck * 16 + (lh & 1) * 8) = pk;
+              }
+            }
+          }
+        } else {
+          const int pp = u - KT1;                  // compile-time after unrolling
+          if (128 * pp + 64 * wn < C)              // (wave-uniform) the last piece is 64 columns wide
+            mma_tile(sb, acc2[pp]);
+        }
+      }
+      slot = slot + 1 == NSTAGE ? 0 : slot + 1;
+    }
+  }
+
+  // ---- final epilogue: + bias + residual (= the kernel's own input rows), bf16 store --------------------
+#pragma unroll
+  for (int pp = 0; pp < NP2; ++pp) {
+    if (128 * pp + 64 * wn >= C) continue;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + 32 * wm + 16 * i + lr;
+      if (m >= p.M) continue;
+      const bf16_t* xr = (const bf16_t*)p.x + (int64_t)m * p.ldx;
+      bf16_t* orow = (bf16_t*)p.out + (int64_t)m * p.ldo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
+        const f32x4 bb = *(const f32x4*)(p.b2 + n);
+        const u32x2 rr = *(const u32x2*)(xr + n);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc2[pp][i][j][r] + bb[r];
+        v[0] += __uint_as_float(rr[0] << 16); v[1] += __uint_as_float(rr[0] & 0xffff0000u);
+        v[2] += __uint_as_float(rr[1] << 16); v[3] += __uint_as_float(rr[1] & 0xffff0000u);
+        u32x2 pk;
+        pk[0] = pack_bf2(v[0], v[1]);
+        pk[1] = pack_bf2(v[2], v[3]);
+        *(u32x2*)(orow + n) = pk;
+      }
+    }
+  }
+#endif
+}
+
+}  // namespace
+
+extern "C" int ldm_ffn_geglu_supported(int M, int C, int dtype) {
+  return (dtype == LDM_BF16 && C == 320 && M > 0) ? 1 : 0;
+}
+
+extern "C" int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const float* aux, const void* w2,
+                             const float* b2, void* out, int64_t ldo, int M, int C, float eps, int dtype,
+                             void* stream) {
+  LDM_CHECK_ARG(x && w1 && aux && w2 && b2 && out, "ldm_ffn_geglu: null pointer");
+  LDM_CHECK_ARG(ldm_ffn_geglu_supported(M, C, dtype), "ldm_ffn_geglu: bf16 with C = 320 only (M=%d C=%d dtype=%d)", M, C, dtype);
+  LDM_CHECK_ARG(ldx % 8 == 0 && ldo % 4 == 0 && ldx >= C && ldo >= C && eps > 0.f, "ldm_ffn_geglu: row strides / eps");
+  auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+  LDM_CHECK_ARG(al16(x) && al16(w1) && al16(aux) && al16(w2) && al16(b2) && ((uintptr_t)out % 8) == 0,
+                "ldm_ffn_geglu: pointers must be 16-byte aligned (out: 8)");
+  const int64_t xb = (((int64_t)M - 1) * ldx + C) * 2;
+  LDM_CHECK_ARG(xb < (1ll << 31), "ldm_ffn_geglu: input extent must be < 2 GiB");
+  FfnArgs a;
+  a.x = (const char*)x; a.w1 = (const char*)w1; a.aux = (const char*)aux; a.w2 = (const char*)w2; a.b2 = b2;
+  a.out = (char*)out; a.ldx = ldx; a.ldo = ldo;
+  a.x_bytes = (uint32_t)xb; a.w1_bytes = (uint32_t)(8 * C * C * 2); a.w2_bytes = (uint32_t)(C * 4 * C * 2);
+  a.aux_bytes = (uint32_t)(8 * C / 128 * 1024);
+  a.M = M; a.eps = eps;
+  dim3 grid((M + 127) / 128);
+  hipLaunchKernelGGL((ffn_geglu_kernel<320>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  return ldm_launch_status("ldm_ffn_geglu");
+}

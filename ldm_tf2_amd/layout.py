@@ -111,6 +111,14 @@ def ln_fold(wt_nk, gamma, beta, bias, dtype, device, row_scale=None, bias_extra=
   return wq.contiguous().to(device), cs.contiguous().to(device), bb.contiguous().to(device)
 
 
+def ffn_aux(cs, bias):
+  """ldm_ffn_geglu's `aux`: per 128 rows of the folded GEGLU weights their column sums (128) then their
+  folded bias (128), float32 [8C / 128, 256]."""
+  n = cs.numel()
+  assert n % 128 == 0 and bias.numel() == n
+  return torch.cat([cs.reshape(n // 128, 128), bias.reshape(n // 128, 128)], 1).contiguous()
+
+
 def vec(a, device):
   return _dev(a, torch.float32, device)
 

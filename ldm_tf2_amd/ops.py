@@ -687,6 +687,24 @@ def attention(q, k, vt, out, heads, sp, scale, matrix_softmax=False):
   return out
 
 
+def ffn_geglu_supported(x):
+  Cc = x.shape[-1]
+  return bool(lib.ldm_ffn_geglu_supported(x.numel() // Cc, Cc, code(x.dtype)))
+
+
+def ffn_geglu(x, w1, aux, w2, b2, out, eps):
+  """out = x + b2 + W2 (a * gelu(g)), (a | g) = W1 LayerNorm(x) + b1: the transformer block's feed-forward as
+  one launch per 128-row panel (ldm_ffn_geglu: bf16, C = 320).  w1 / aux from layout.ln_fold + layout.ffn_aux."""
+  Cc = x.shape[-1]
+  M = x.numel() // Cc
+  assert out.dtype == x.dtype and tuple(out.shape) == tuple(x.shape)
+  assert tuple(w1.shape) == (8 * Cc, Cc) and tuple(w2.shape) == (Cc, 4 * Cc) and w1.is_contiguous() and w2.is_contiguous()
+  assert aux.dtype == torch.float32 and aux.numel() == 8 * Cc * 2 and aux.is_contiguous()
+  check(lib.ldm_ffn_geglu(_ptr(x), row_ld(x), _ptr(w1), _ptr(aux), _ptr(w2), _ptr(_f32(b2, "b2")), _ptr(out),
+                          row_ld(out), M, Cc, float(eps), code(x.dtype), _stream()), "ldm_ffn_geglu")
+  return out
+
+
 def time_embedding(out, channels, t_rows=None, steps=None, index=None):
   rows = out.shape[0]
   check(lib.ldm_time_embedding(_ptr(t_rows), _ptr(steps), _ptr(index), _ptr(_f32(out, "out")), rows,

@@ -105,6 +105,10 @@ class _ST:
           q2=L.ln_fold(L.split_kernel(w[a2 + "/query/kernel"], sp, f32, cpu), lnp[1][0], lnp[1][1], None, dtype, dev,
                        row_scale=q_scale),
           geglu=L.ln_fold(gw, lnp[2][0], lnp[2][1], gb.numpy(), dtype, dev))
+    # the whole feed-forward as one row-panel launch (ldm_ffn_geglu): C = 320 blocks, with the fold
+    self.ffn_aux = None
+    if self.fold is not None and c == 320:
+      self.ffn_aux = L.ffn_aux(self.fold["geglu"][1], self.fold["geglu"][2])
     self.ctx_k = self.ctx_vt = None     # filled by UNet.set_context
 
 
@@ -119,7 +123,7 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True, matrix_softmax=True, gn_single_launch=True):
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -145,6 +149,8 @@ class UNet:
     self._fold_ln = dtype == torch.bfloat16 and bool(fold_layernorm) and not self._fuse_ln
     self._fold_min_rows = int(fold_min_rows)
     self._matrix_softmax = bool(matrix_softmax)   # ldm_attention_ms on the 40-wide heads (with the fold; A/B: False)
+    self._fused_ffn = bool(fused_ffn)             # ldm_ffn_geglu on the C = 320 blocks (needs the fold; A/B: False)
+    self._ffn_min_rows = int(ffn_min_rows)        # ... from 192 panels of 128 rows on (3/4 of the CUs busy)
     self._gn_single = bool(gn_single_launch)      # False: partial-sums + apply launches everywhere (A/B)
     self._defer_reduce = bool(defer_reduce)   # split-K reduces fused into the consuming GroupNorm (A/B: False)
     self._pend = None
@@ -390,6 +396,12 @@ class UNet:
     ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
     ops.linear(att, st.o2[0], ha, bias=st.o2[1], residual=hb, ln=lnp(2))
     # GEGLU feed-forward (unet.py:313, :323-325, :335-338)
+    if (fold is not None and st.ffn_aux is not None and self._fused_ffn and R * T >= self._ffn_min_rows):
+      # LayerNorm -> GEGLU -> FF-out + residual as ONE row-panel launch: the [R*T, 4C] hidden activation
+      # never reaches HBM (unet.py:313)
+      ops.ffn_geglu(ha, fold["geglu"][0], st.ffn_aux, st.ff_out[0], st.ff_out[1], hb, LN_EPS)
+      ops.linear(hb, st.proj_out[0], out, bias=st.proj_out[1], residual=x)
+      return out
     ff = B_.get("st_ff", (R, T, 4 * c), dt)
     if fold is not None:
       ops.linear(ha, fold["geglu"][0], ff, bias=fold["geglu"][2], act=ops.ACT_GEGLU,

@@ -272,3 +272,67 @@ def test_attention_matrix_softmax_reference_moves(dev):
   _ms_case(dev, 1, 2, 256, 256, spike=True)
   _ms_case(dev, 1, 2, 128, 200, big_offset=40.0)
   _ms_case(dev, 1, 2, 128, 200, big_offset=-40.0)
+
+
+# ---- fused feed-forward row-panel kernel (ldm_ffn_geglu) ----------------------------------------------
+@pytest.mark.parametrize("M", [256, 1000, 4096])
+def test_ffn_geglu_row_panel_kernel(dev, M):
+  """x + Dense(a * gelu(g)) with (a | g) = Dense(LayerNorm(x)) (unet.py:313, :323-325, :335-338) as one launch,
+  against the oracle and against the two-launch form (LayerNorm-folded GEGLU GEMM, then FF-out + residual)."""
+  o = ops()
+  C = 320
+  x, gamma, beta = _ln_case(M, C, 70, 2.0)
+  k1 = rnd((C, 8 * C), 71, C ** -0.5).numpy()
+  b1 = rnd((8 * C,), 72).numpy()
+  k2 = rnd((4 * C, C), 73, (4 * C) ** -0.5).numpy()
+  b2 = rnd((C,), 74)
+  y = O.dense(O.layer_norm(x.float(), gamma, beta, eps=1e-5), torch.from_numpy(k1), torch.from_numpy(b1))
+  ref = x.float() + O.dense(y[:, :4 * C] * O.gelu(y[:, 4 * C:]), torch.from_numpy(k2), b2)
+  gw, gb = L.geglu_kernel(k1, b1, torch.float32, "cpu")
+  w1, cs, bb = L.ln_fold(gw, gamma.numpy(), beta.numpy(), gb.numpy(), BF, dev)
+  w2 = L.dense_kernel(k2, BF, dev)
+  aux = L.ffn_aux(cs, bb)
+  xd = x.to(dev)
+  out = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+  assert o.ffn_geglu_supported(xd)
+  o.ffn_geglu(xd, w1, aux, w2, b2.to(dev), out, 1e-5)
+  # two-launch form on the same folded weights
+  ff = torch.empty(M, 4 * C, dtype=BF, device=dev)
+  o.linear(xd, w1, ff, bias=bb, act=o.ACT_GEGLU, ln_fold=(cs, 1e-5))
+  out2 = torch.empty(M, C, dtype=BF, device=dev)
+  o.linear(ff, w2, out2, bias=b2.to(dev), residual=xd)
+  r, r2, d = rel(out, ref), rel(out2, ref), rel(out, out2.float().cpu())
+  print(f"ffn_geglu M={M}: rel {r:.3e} (two launches {r2:.3e}; fused vs two launches {d:.3e})")
+  assert r < 4e-3 and r <= r2 * 1.2 + 1e-4 and d < 3e-3
+
+
+def test_unet_fused_ffn_matches_the_unfused_unet(dev):
+  """A C = 320 U-Net level through ldm_ffn_geglu (ffn_min_rows=1) against the oracle and the unfused launches."""
+  from ldm_tf2_amd.unet import UNet
+  cfg = dict(model_channels=320, out_channels=4, num_blocks=1, channel_mult=(1,), num_heads=8)
+  ctx_dim = 128
+  w = Wt.init_weights(Wt.unet_manifest(context_dim=ctx_dim, **cfg), seed=7, mode="random", scope="unet")
+  g = np.random.default_rng(8)
+  x = g.standard_normal((2, 32, 32, 4)).astype(np.float32)
+  ctx = g.standard_normal((2, 77, ctx_dim)).astype(np.float32)
+  t = np.array([981, 21], dtype=np.int32)
+  ref = O.unet_forward(x, t, ctx, w, num_heads=8)
+  outs = {}
+  for fused in (True, False):
+    unet = UNet(**cfg, weights=w, dtype=BF, device=dev, context_dim=ctx_dim, fold_min_rows=1, fused_ffn=fused, ffn_min_rows=1)
+    assert unet.sts[0].ffn_aux is not None and unet.sts[0].ms
+    calls = [0]
+    orig = ops().lib.ldm_ffn_geglu
+
+    def counted(*a, _orig=orig, _n=calls):
+      _n[0] += 1
+      return _orig(*a)
+
+    ops().lib.ldm_ffn_geglu = counted
+    try:
+      outs[fused] = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
+    finally:
+      ops().lib.ldm_ffn_geglu = orig
+    assert (calls[0] > 0) == fused
+    print(f"C=320 U-Net, fused feed-forward={fused}: rel {rel(outs[fused], ref):.3e} ({calls[0]} fused launches)")
+  assert rel(outs[True], ref) < 4e-2 and rel(outs[True], ref) <= rel(outs[False], ref) * 1.5

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""ldm_ffn_geglu (LayerNorm -> GEGLU -> FF-out + residual as one row-panel launch) against the two launches it
+replaces, M rows of C = 320, graph-replayed best of 5 (tools.gemm_bench.time_fn).
+
+    python tools/ffn_probe.py [M ...]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ldm_tf2_amd import layout as L, ops  # noqa: E402
+from tools.gemm_bench import time_fn  # noqa: E402
+
+dev = torch.device("cuda:0")
+C = 320
+g = torch.Generator().manual_seed(0)
+k1 = (torch.randn(C, 8 * C, generator=g) * C ** -0.5).numpy()
+b1 = torch.randn(8 * C, generator=g).numpy()
+k2 = (torch.randn(4 * C, C, generator=g) * (4 * C) ** -0.5).numpy()
+b2 = torch.randn(C, generator=g).to(dev)
+gw, gb = L.geglu_kernel(k1, b1, torch.float32, "cpu")
+w1, cs, bb = L.ln_fold(gw, np.ones(C, np.float32), np.zeros(C, np.float32), gb.numpy(), torch.bfloat16, dev)
+w2 = L.dense_kernel(k2, torch.bfloat16, dev)
+aux = L.ffn_aux(cs, bb)
+for M in [int(a) for a in sys.argv[1:]] or [32768, 16384]:
+  x = torch.randn(M, C, device=dev).to(torch.bfloat16)
+  out = torch.empty_like(x)
+  ff = torch.empty(M, 4 * C, dtype=torch.bfloat16, device=dev)
+  t_f = time_fn(lambda: ops.ffn_geglu(x, w1, aux, w2, b2, out, 1e-5), 5)
+
+  def two():
+    ops.linear(x, w1, ff, bias=bb, act=ops.ACT_GEGLU, ln_fold=(cs, 1e-5), tile=14)
+    ops.linear(ff, w2, out, bias=b2, residual=x, tile=13)
+
+  t_2 = time_fn(two, 5)
+  gf = 2.0 * M * C * 8 * C * 1e-9 + 2.0 * M * 4 * C * C * 1e-9
+  print(f"M={M}: fused {t_f * 1e3:7.1f} us ({gf / t_f:5.0f} TFLOP/s)   two launches {t_2 * 1e3:7.1f} us ({gf / t_2:5.0f} TFLOP/s)")
