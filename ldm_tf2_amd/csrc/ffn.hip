@@ -20,6 +20,7 @@
 //     load (those would drain the DMA queue at their first use).
 // Work per workgroup: 160 barrier periods of 16 MFMAs (16x16x32) per wave; 256 workgroups for M = 32768.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -34,7 +35,16 @@ struct FfnArgs {
   uint32_t x_bytes, w1_bytes, w2_bytes, aux_bytes;
   int M;
   float eps;
+#ifdef LDM_TOOLS_BUILD
+  int dbg;             // timing ablations (tools build only): 1 no MFMA, 2 no weight staging, 4 no GEGLU epilogue, 8 no B fragment reads
+#endif
 };
+
+#ifdef LDM_TOOLS_BUILD
+#define LDM_FFN_DBG(p) ((p).dbg)
+#else
+#define LDM_FFN_DBG(p) 0
+#endif
 
 constexpr uint32_t kOOBf = 0x80000000u;
 
@@ -194,11 +204,17 @@ __global__ __launch_bounds__(512) void ffn_geglu_kernel(FfnArgs p) {
       for (int i = 0; i < 2; ++i) fa[kg][i] = *(const u32x4*)(sa + offA[kg][i]);
   };
   auto mma_tile = [&](const char* sb, f32x4 (&acc)[2][4]) {
+    if (LDM_FFN_DBG(p) & 1) return;
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg) {
       u32x4 fb[4];
+      if (LDM_FFN_DBG(p) & 8) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(sb + offB[kg][j]);
+        for (int j = 0; j < 4; ++j) fb[j] = u32x4{(uint32_t)lane, 1u, 2u, 3u};
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(sb + offB[kg][j]);
+      }
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -229,7 +245,7 @@ __global__ __launch_bounds__(512) void ffn_geglu_kernel(FfnArgs p) {
       const char* sb = smem + OFF_R + slot * STG;
       {
         int sn = slot + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
-        if (s + 2 < S) issue(s + 2, sn);
+        if (s + 2 < S && !(LDM_FFN_DBG(p) & 2)) issue(s + 2, sn);
       }
       {
         if (u < KT1) {
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(512) void ffn_geglu_kernel(FfnArgs p) {
               for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
           mma_tile(sb, acc1);
-          if (u == KT1 - 1) {
+          if (u == KT1 - 1 && !(LDM_FFN_DBG(p) & 4)) {
             // GEGLU of the chunk: blocks 0, 1 = value, blocks 2, 3 = gate (one 64-row block of the interleaved
             // weights per wave); LayerNorm fold: rstd acc + (b' - rstd mean cs); result -> bf16 -> hidden tile
             const float* aux = (const float*)(sb + TILE);
@@ -332,6 +348,9 @@ extern "C" int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const f
   a.x_bytes = (uint32_t)xb; a.w1_bytes = (uint32_t)(8 * C * C * 2); a.w2_bytes = (uint32_t)(C * 4 * C * 2);
   a.aux_bytes = (uint32_t)(8 * C / 128 * 1024);
   a.M = M; a.eps = eps;
+#ifdef LDM_TOOLS_BUILD
+  { static const int dbg = getenv("LDM_FFN_DEBUG") ? atoi(getenv("LDM_FFN_DEBUG")) : 0; a.dbg = dbg; }
+#endif
   dim3 grid((M + 127) / 128);
   hipLaunchKernelGGL((ffn_geglu_kernel<320>), grid, dim3(512), 0, (hipStream_t)stream, a);
   return ldm_launch_status("ldm_ffn_geglu");

@@ -11,6 +11,8 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get("LDM_FFN_DEBUG"):             # timing ablations: tools build only (make tools)
+  import tools.toolslib  # noqa: F401,E402
 from ldm_tf2_amd import layout as L, ops  # noqa: E402
 from tools.gemm_bench import time_fn  # noqa: E402
 
@@ -37,4 +39,4 @@ for M in [int(a) for a in sys.argv[1:]] or [32768, 16384]:
 
   t_2 = time_fn(two, 5)
   gf = 2.0 * M * C * 8 * C * 1e-9 + 2.0 * M * 4 * C * C * 1e-9
-  print(f"M={M}: fused {t_f * 1e3:7.1f} us ({gf / t_f:5.0f} TFLOP/s)   two launches {t_2 * 1e3:7.1f} us ({gf / t_2:5.0f} TFLOP/s)")
+  print(f"dbg={os.environ.get('LDM_FFN_DEBUG', '0')} M={M}: fused {t_f * 1e3:7.1f} us ({gf / t_f:5.0f} TFLOP/s)   two launches {t_2 * 1e3:7.1f} us ({gf / t_2:5.0f} TFLOP/s)")
