@@ -287,6 +287,15 @@ int ldm_attention_ms(const void* q, int64_t ldq, int64_t q_bs, const void* k, in
  * Same arithmetic as ldm_gemm(ln_cs, GEGLU) followed by ldm_gemm(residual) except that the hidden
  * activation is rounded to bf16 in LDS instead of HBM (identical rounding points).
  */
+/* The same with the neighbouring products folded in (one launch for the tail of a SpatialTransformer block):
+ *     h   = r0 + bo + Wo . att        cross-attention output projection + residual (unet.py:312; att [M][K0], K0 = 384)
+ *     y   = feed-forward(h)           as above (h and y live only in LDS)
+ *     out = r1 + bp + Wp . y          proj_out + the block's input as residual (unet.py:363-365)
+ * wo [C][K0], wp [C][C] bf16 (K contiguous); r0, r1, out [M][C] bf16. */
+int ldm_st_tail(const void* att, int64_t lda, int K0, const void* wo, const float* bo, const void* r0,
+                int64_t ldr0, const void* w1, const float* aux, const void* w2, const float* b2,
+                const void* wp, const float* bp, const void* r1, int64_t ldr1, void* out, int64_t ldo,
+                int M, int C, float eps, int dtype, void* stream);
 int ldm_ffn_geglu_supported(int M, int C, int dtype);
 int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const float* aux, const void* w2,
                   const float* b2, void* out, int64_t ldo, int M, int C, float eps, int dtype, void* stream);

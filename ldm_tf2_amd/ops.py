@@ -705,6 +705,23 @@ def ffn_geglu(x, w1, aux, w2, b2, out, eps):
   return out
 
 
+def st_tail(att, wo, bo, r0, w1, aux, w2, b2, wp, bp, r1, out, eps):
+  """out = r1 + bp + Wp y,  y = feed-forward(h),  h = r0 + bo + Wo att: the o-projection of the cross-attention, the
+  transformer block's feed-forward and the SpatialTransformer's proj_out as ONE row-panel launch (ldm_st_tail:
+  bf16, C = 320, attention width 384).  h and y never reach HBM."""
+  Cc = out.shape[-1]
+  K0 = att.shape[-1]
+  M = out.numel() // Cc
+  assert att.numel() // K0 == M and att.dtype == out.dtype == r0.dtype == r1.dtype
+  assert tuple(wo.shape) == (Cc, K0) and tuple(wp.shape) == (Cc, Cc) and wo.is_contiguous() and wp.is_contiguous()
+  assert tuple(w1.shape) == (8 * Cc, Cc) and tuple(w2.shape) == (Cc, 4 * Cc) and w1.is_contiguous() and w2.is_contiguous()
+  assert aux.dtype == torch.float32 and aux.numel() == 8 * Cc * 2 and aux.is_contiguous()
+  check(lib.ldm_st_tail(_ptr(att), row_ld(att), K0, _ptr(wo), _ptr(_f32(bo, "bo")), _ptr(r0), row_ld(r0), _ptr(w1),
+                        _ptr(aux), _ptr(w2), _ptr(_f32(b2, "b2")), _ptr(wp), _ptr(_f32(bp, "bp")), _ptr(r1), row_ld(r1),
+                        _ptr(out), row_ld(out), M, Cc, float(eps), code(out.dtype), _stream()), "ldm_st_tail")
+  return out
+
+
 def time_embedding(out, channels, t_rows=None, steps=None, index=None):
   rows = out.shape[0]
   check(lib.ldm_time_embedding(_ptr(t_rows), _ptr(steps), _ptr(index), _ptr(_f32(out, "out")), rows,

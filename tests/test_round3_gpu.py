@@ -306,8 +306,53 @@ def test_ffn_geglu_row_panel_kernel(dev, M):
   assert r < 4e-3 and r <= r2 * 1.2 + 1e-4 and d < 3e-3
 
 
-def test_unet_fused_ffn_matches_the_unfused_unet(dev):
-  """A C = 320 U-Net level through ldm_ffn_geglu (ffn_min_rows=1) against the oracle and the unfused launches."""
+@pytest.mark.parametrize("M", [128, 1000, 4096])
+def test_st_tail_row_panel_kernel(dev, M):
+  """o-projection + residual, feed-forward, proj_out + residual (unet.py:312-313, :363-365) as ONE launch, against
+  the oracle and against the four launches it replaces."""
+  o = ops()
+  C, K0 = 320, 384
+  att = rnd((M, K0), 80)
+  r0, gamma, beta = _ln_case(M, C, 81, 2.0)
+  r1 = rnd((M, C), 82)
+  ko = rnd((K0, C), 83, K0 ** -0.5).numpy()
+  bo = rnd((C,), 84)
+  k1 = rnd((C, 8 * C), 85, C ** -0.5).numpy()
+  b1 = rnd((8 * C,), 86).numpy()
+  k2 = rnd((4 * C, C), 87, (4 * C) ** -0.5).numpy()
+  b2 = rnd((C,), 88)
+  kp = rnd((C, C), 89, C ** -0.5).numpy()
+  bp = rnd((C,), 90)
+  attb, r0b, r1b = att.to(BF), r0.to(BF), r1.to(BF)
+  h = r0b.float() + O.dense(attb.float(), torch.from_numpy(ko), bo)
+  y = O.dense(O.layer_norm(h, gamma, beta, eps=1e-5), torch.from_numpy(k1), torch.from_numpy(b1))
+  y = h + O.dense(y[:, :4 * C] * O.gelu(y[:, 4 * C:]), torch.from_numpy(k2), b2)
+  ref = r1b.float() + O.dense(y, torch.from_numpy(kp), bp)
+  gw, gb = L.geglu_kernel(k1, b1, torch.float32, "cpu")
+  w1, cs, bb = L.ln_fold(gw, gamma.numpy(), beta.numpy(), gb.numpy(), BF, dev)
+  wo, w2, wp = (L.dense_kernel(k, BF, dev) for k in (ko, k2, kp))
+  aux = L.ffn_aux(cs, bb)
+  ad, r0d, r1d = attb.to(dev), r0b.to(dev), r1b.to(dev)
+  out = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+  o.st_tail(ad, wo, bo.to(dev), r0d, w1, aux, w2, b2.to(dev), wp, bp.to(dev), r1d, out, 1e-5)
+  hd = torch.empty(M, C, dtype=BF, device=dev)
+  o.linear(ad, wo, hd, bias=bo.to(dev), residual=r0d)
+  ff = torch.empty(M, 4 * C, dtype=BF, device=dev)
+  o.linear(hd, w1, ff, bias=bb, act=o.ACT_GEGLU, ln_fold=(cs, 1e-5))
+  yd = torch.empty(M, C, dtype=BF, device=dev)
+  o.linear(ff, w2, yd, bias=b2.to(dev), residual=hd)
+  out4 = torch.empty(M, C, dtype=BF, device=dev)
+  o.linear(yd, wp, out4, bias=bp.to(dev), residual=r1d)
+  r, r4, d = rel(out, ref), rel(out4, ref), rel(out, out4.float().cpu())
+  print(f"st_tail M={M}: rel {r:.3e} (four launches {r4:.3e}; fused vs four launches {d:.3e})")
+  assert torch.isfinite(out.float()).all()
+  assert r < 5e-3 and r <= r4 * 1.2 + 1e-4 and d < 5e-3
+
+
+@pytest.mark.parametrize("fused,tail", [(True, True), (True, False), (False, False)])
+def test_unet_fused_ffn_matches_the_unfused_unet(dev, fused, tail):
+  """A C = 320 U-Net level through ldm_st_tail / ldm_ffn_geglu (ffn_min_rows=1) against the oracle and the unfused
+  launches."""
   from ldm_tf2_amd.unet import UNet
   cfg = dict(model_channels=320, out_channels=4, num_blocks=1, channel_mult=(1,), num_heads=8)
   ctx_dim = 128
@@ -317,22 +362,23 @@ def test_unet_fused_ffn_matches_the_unfused_unet(dev):
   ctx = g.standard_normal((2, 77, ctx_dim)).astype(np.float32)
   t = np.array([981, 21], dtype=np.int32)
   ref = O.unet_forward(x, t, ctx, w, num_heads=8)
-  outs = {}
-  for fused in (True, False):
-    unet = UNet(**cfg, weights=w, dtype=BF, device=dev, context_dim=ctx_dim, fold_min_rows=1, fused_ffn=fused, ffn_min_rows=1)
-    assert unet.sts[0].ffn_aux is not None and unet.sts[0].ms
-    calls = [0]
-    orig = ops().lib.ldm_ffn_geglu
-
-    def counted(*a, _orig=orig, _n=calls):
-      _n[0] += 1
+  base = UNet(**cfg, weights=w, dtype=BF, device=dev, context_dim=ctx_dim, fold_min_rows=1, fused_ffn=False)
+  out0 = base(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
+  unet = UNet(**cfg, weights=w, dtype=BF, device=dev, context_dim=ctx_dim, fold_min_rows=1, fused_ffn=fused,
+              fused_tail=tail, ffn_min_rows=1)
+  assert unet.sts[0].ffn_aux is not None and unet.sts[0].ms
+  calls = {"ldm_ffn_geglu": 0, "ldm_st_tail": 0}
+  origs = {k: getattr(ops().lib, k) for k in calls}
+  for k in calls:
+    def counted(*a, _orig=origs[k], _k=k):
+      calls[_k] += 1
       return _orig(*a)
-
-    ops().lib.ldm_ffn_geglu = counted
-    try:
-      outs[fused] = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
-    finally:
-      ops().lib.ldm_ffn_geglu = orig
-    assert (calls[0] > 0) == fused
-    print(f"C=320 U-Net, fused feed-forward={fused}: rel {rel(outs[fused], ref):.3e} ({calls[0]} fused launches)")
-  assert rel(outs[True], ref) < 4e-2 and rel(outs[True], ref) <= rel(outs[False], ref) * 1.5
+    setattr(ops().lib, k, counted)
+  try:
+    out = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
+  finally:
+    for k in calls:
+      setattr(ops().lib, k, origs[k])
+  assert (calls["ldm_st_tail"] > 0) == (fused and tail) and (calls["ldm_ffn_geglu"] > 0) == (fused and not tail)
+  print(f"C=320 U-Net, fused feed-forward={fused} tail={tail}: rel {rel(out, ref):.3e} (unfused {rel(out0, ref):.3e}; {calls})")
+  assert rel(out, ref) < 4e-2 and rel(out, ref) <= rel(out0, ref) * 1.5

@@ -26,6 +26,8 @@ b2 = torch.randn(C, generator=g).to(dev)
 gw, gb = L.geglu_kernel(k1, b1, torch.float32, "cpu")
 w1, cs, bb = L.ln_fold(gw, np.ones(C, np.float32), np.zeros(C, np.float32), gb.numpy(), torch.bfloat16, dev)
 w2 = L.dense_kernel(k2, torch.bfloat16, dev)
+wo = L.dense_kernel((torch.randn(384, C, generator=g) * 384 ** -0.5).numpy(), torch.bfloat16, dev)
+wp = L.dense_kernel((torch.randn(C, C, generator=g) * C ** -0.5).numpy(), torch.bfloat16, dev)
 aux = L.ffn_aux(cs, bb)
 for M in [int(a) for a in sys.argv[1:]] or [32768, 16384]:
   x = torch.randn(M, C, device=dev).to(torch.bfloat16)
@@ -40,3 +42,17 @@ for M in [int(a) for a in sys.argv[1:]] or [32768, 16384]:
   t_2 = time_fn(two, 5)
   gf = 2.0 * M * C * 8 * C * 1e-9 + 2.0 * M * 4 * C * C * 1e-9
   print(f"dbg={os.environ.get('LDM_FFN_DEBUG', '0')} M={M}: fused {t_f * 1e3:7.1f} us ({gf / t_f:5.0f} TFLOP/s)   two launches {t_2 * 1e3:7.1f} us ({gf / t_2:5.0f} TFLOP/s)")
+  att = torch.randn(M, 384, device=dev).to(torch.bfloat16)
+  r1 = torch.randn(M, C, device=dev).to(torch.bfloat16)
+  h, y = torch.empty_like(x), torch.empty_like(x)
+  t_t = time_fn(lambda: ops.st_tail(att, wo, b2, x, w1, aux, w2, b2, wp, b2, r1, out, 1e-5), 5)
+
+  def four():
+    ops.linear(att, wo, h, bias=b2, residual=x)
+    ops.linear(h, w1, ff, bias=bb, act=ops.ACT_GEGLU, ln_fold=(cs, 1e-5), tile=14)
+    ops.linear(ff, w2, y, bias=b2, residual=h, tile=13)
+    ops.linear(y, wp, out, bias=b2, residual=r1)
+
+  t_4 = time_fn(four, 5)
+  gf += 2.0 * M * C * (384 + C) * 1e-9
+  print(f"      st_tail (o-projection + feed-forward + proj_out): {t_t * 1e3:7.1f} us ({gf / t_t:5.0f} TFLOP/s)   four launches {t_4 * 1e3:7.1f} us")
