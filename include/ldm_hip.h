@@ -296,6 +296,26 @@ int ldm_st_tail(const void* att, int64_t lda, int K0, const void* wo, const floa
                 int64_t ldr0, const void* w1, const float* aux, const void* w2, const float* b2,
                 const void* wp, const float* bp, const void* r1, int64_t ldr1, void* out, int64_t ldo,
                 int M, int C, float eps, int dtype, void* stream);
+/* ldm_st_tail with the cross-attention itself in front (unet.py:273-291, :311): the input rows are the QUERY
+ * projection q [M][K0] in ldm_attention_ms's layout (exp2-domain logits, 8 heads of 40 padded to 48); ctx_k
+ * [R][Tk][K0] / ctx_vt [R][K0][ldv] are the context keys / values^T of the M / T samples in the same layout (Tk <= 80:
+ * one key tile, plain softmax; T query rows per sample, a multiple of 128).  The attention runs in place in the LDS
+ * panel, its output never reaches HBM. */
+int ldm_st_xtail(const void* q, int64_t ldq, int K0, const void* ctx_k, const void* ctx_vt, int Tk, int ldv, int T,
+                 const void* wo, const float* bo, const void* r0, int64_t ldr0, const void* w1, const float* aux,
+                 const void* w2, const float* b2, const void* wp, const float* bp, const void* r1, int64_t ldr1,
+                 void* out, int64_t ldo, int M, int C, float eps, int dtype, void* stream);
+/* ... and with the block's middle in front of that (unet.py:310-311): the input rows are the SELF-attention's output
+ * att [M][K0]; h1 = r0 + bo1 + Wo1 . att and the LayerNorm-folded query projection q = Wq . LayerNorm(h1) + bq (wq
+ * [K0][C] gamma-folded with the attention scale * log2(e) and the padded rows of ldm_attention_ms's layout, qcs its
+ * column sums, qb the folded bias: layout.ln_fold) run first; h1 is the residual of the second o-projection.  One
+ * launch from the self-attention's output to the SpatialTransformer's output; `out` doubles as scratch for h1 and
+ * must not alias an input. */
+int ldm_st_block(const void* att, int64_t lda, int K0, const void* wo1, const float* bo1, const void* r0, int64_t ldr0,
+                 const void* wq, const float* qcs, const float* qb, const void* ctx_k, const void* ctx_vt, int Tk,
+                 int ldv, int T, const void* wo2, const float* bo2, const void* w1, const float* aux, const void* w2,
+                 const float* b2, const void* wp, const float* bp, const void* r1, int64_t ldr1, void* out, int64_t ldo,
+                 int M, int C, float eps, int dtype, void* stream);
 int ldm_ffn_geglu_supported(int M, int C, int dtype);
 int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const float* aux, const void* w2,
                   const float* b2, void* out, int64_t ldo, int M, int C, float eps, int dtype, void* stream);

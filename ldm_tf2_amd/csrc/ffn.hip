@@ -54,6 +54,19 @@ struct FfnArgs {
   const char* r1;      // [M][C] bf16 residual of proj_out, row stride ldr1
   int64_t ldr1;
   uint32_t wp_bytes;
+  // FRONT: the self-attention's o-projection (fw [C][K0], fb, residual r0) and the cross-attention's LayerNorm-folded
+  // query projection (qw [K0][C] gamma-folded, qcs its column sums, qb the folded bias) run first; the o-projection
+  // of PRE then takes its residual from the rows this kernel parked in `out`
+  const char* fw;
+  const float* fb;
+  const char* qw;
+  const float* qcs;
+  const float* qb;
+  uint32_t fw_bytes, qw_bytes, out_bytes;
+  // XATT: x = the cross-attention's QUERY rows (ldm_attention_ms layout); keys [R][Tk][K0] / values^T [R][K0][ldv]
+  const char* ctx_k;
+  const char* ctx_vt;
+  int Tk, ldv, T;      // keys per sample, V^T row stride, query rows per sample (multiple of 128)
 #ifdef LDM_TOOLS_BUILD
   int dbg;             // timing ablations (tools build only): 1 no MFMA, 2 no weight staging, 4 no GEGLU epilogue, 8 no B fragment reads
 #endif
@@ -67,11 +80,16 @@ struct FfnArgs {
 
 constexpr uint32_t kOOBf = 0x80000000u;
 
-// C: channels (320); KT0: K-tiles of the PRE product (attention width / 64; 0 = no PRE phase); POST: proj_out phase
-template <int C, int KT0, bool POST>
+// C: channels (320); KT0: K-tiles of the PRE product (attention width / 64; 0 = no PRE phase);
+// KIND 0: feed-forward only, 1: + proj_out (POST);
+// 3 (XATT): as 1, but the input rows are the cross-attention's QUERIES and the attention itself (unet.py:273-291
+// against the <= 80 context keys of the panel's sample) runs first, in place in the LDS panel;
+// 4 (FRONT): as 3, but the input rows are the SELF-attention's output: its o-projection + residual and the
+// LayerNorm-folded query projection (unet.py:310-311) run first and leave the queries in the panel
+template <int C, int KT0, int KIND>
 __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr bool PRE = KT0 > 0;
+  constexpr bool PRE = KT0 > 0, POST = KIND != 0, XATT = KIND >= 3, FRONT = KIND == 4;
   constexpr int BM = 128;
   constexpr int KT1 = C / 64;                  // K-tiles of a product over the channels (5)
   constexpr int HID = 4 * C, NCH = HID / 64;   // hidden width, chunks of 64 hidden units (20)
@@ -85,9 +103,12 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
   constexpr int STG = TILE + 1024;             // ring stage: weight tile + a chunk's (colsum | bias) KB
   constexpr int NSTAGE = 3;
   constexpr int OFF_H = KT1 * TILE, OFF_R = OFF_H + TILE;
-  static_assert(C % 64 == 0 && OFF_R + NSTAGE * STG <= 160 * 1024 && KT0 <= KT1 + 1, "LDS");
+  static_assert(C % 64 == 0 && OFF_R + NSTAGE * STG <= 160 * 1024 && KT0 <= KT1 + 1 && KIND != 2, "LDS");
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  __shared__ __attribute__((aligned(16))) char smem[OFF_R + NSTAGE * STG];
+  constexpr int XIMG = 80 * 768;               // XATT: the sample's keys / values^T image (80 x 768 B = 384 x 160 B)
+  constexpr int SMEM = (XATT && OFF_R + XIMG > OFF_R + NSTAGE * STG) ? OFF_R + XIMG : OFF_R + NSTAGE * STG;
+  static_assert(SMEM <= 160 * 1024 && (!XATT || KT0 == 6), "LDS");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,6 +120,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
   const __amdgpu_buffer_rsrc_t rsW1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w1), 0, p.w1_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.w2), 0, p.w2_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsAux = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.aux), 0, p.aux_bytes, 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsOut =
+      __builtin_amdgcn_make_buffer_rsrc(p.out, 0, FRONT ? p.out_bytes : 0u, 0x00020000);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsWo =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(PRE ? p.wo : p.w1), 0, PRE ? p.wo_bytes : 0u, 0x00020000);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsWp =
@@ -130,11 +153,11 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
                                                  xo[h] == kOOBf ? kOOBf : xo[h] + kt * 128, 0, 0, 0);
   }
   // a weight tile whose rows are the output columns 128 pp .. of an N = C product, K bytes kbytes ..
-  auto issue_rows = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, int pp, int kbytes, int row_pitch) {
+  auto issue_rows = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, int pp, int kbytes, int row_pitch, int nmax) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int n = 128 * pp + srow[h];
-      const uint32_t off = n < C ? (uint32_t)(n * row_pitch + kbytes + sck[h]) : kOOBf;
+      const uint32_t off = n < nmax ? (uint32_t)(n * row_pitch + kbytes + sck[h]) : kOOBf;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + (wave + 8 * h) * 1024), 16, off, 0, 0, 0);
     }
   };
@@ -143,7 +166,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     char* dst = smem + OFF_R + slot * STG;
     if (PRE && s < S0) {
       const int kt = s / NP2, pp = s - kt * NP2;
-      issue_rows(rsWo, dst, pp, kt * 128, KT0 * 128);
+      issue_rows(rsWo, dst, pp, kt * 128, KT0 * 128, C);
     } else if (s < S0 + S1) {
       const int f = s - S0;
       const int c = f / SPC, u = f - c * SPC;
@@ -156,12 +179,12 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
         if (u == KT1 - 1)     // the chunk's (column sums | folded bias): 1 KB, every wave writes the same bytes
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsAux, (lds_ptr)(dst + TILE), 16, (uint32_t)(c * 1024 + lane * 16), 0, 0, 0);
       } else {
-        issue_rows(rsW2, dst, u - KT1, c * 128, HID * 2);
+        issue_rows(rsW2, dst, u - KT1, c * 128, HID * 2, C);
       }
     } else {
       const int g = s - S0 - S1;
       const int kt = g / NP2, pp = g - kt * NP2;
-      issue_rows(rsWp, dst, pp, kt * 128, C * 2);
+      issue_rows(rsWp, dst, pp, kt * 128, C * 2, C);
     }
   };
   // DMAs a wave issues for step s (3 where the chunk's aux KB rides along)
@@ -169,9 +192,6 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     const int f = s - S0;
     return (f >= 0 && f < S1 && (f % SPC) == KT1 - 1) ? 3 : 2;
   };
-
-  issue(0, 0);
-  issue(1, 1);
 
   // ---- fragment addresses ------------------------------------------------------------------------
   int offA[2][2], offB[2][4];       // [k group][block]: byte offsets inside a 128 x 128-byte tile
@@ -198,7 +218,6 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc2[pp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  zero_acc2();
 
   // Operands swapped (D = W_frag x A_frag): the lane owns row 16 i + lr and columns 16 j + 4 lh + r.
   // A fragments (resident panel / hidden tile) are read by read_a BEFORE the period's barrier where they do not
@@ -256,59 +275,9 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     return smem + (n >> 6) * TILE + row * 128 + ck * 16 + (n & 7) * 2;
   };
 
-  // ---- PRE: h = r0 + bo + Wo . att ------------------------------------------------------------------
-  if constexpr (PRE) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the panel's DMAs are older than the two weight tiles
-    for (int kt = 0; kt < KT0; ++kt) {
-#pragma unroll
-      for (int pp = 0; pp < NP2; ++pp) {
-        const int s = kt * NP2 + pp;
-        begin_period(s, false);
-        if (pp == 0) read_a(smem + kt * TILE);           // attention rows (visible after the first barrier)
-        issue_ahead(s);
-        if (128 * pp + 64 * wn < C) mma_tile(smem + OFF_R + slot * STG, acc2[pp]);
-        next_slot();
-      }
-    }
-    __builtin_amdgcn_s_barrier();                        // every wave is done with the attention rows
-    // h -> the panel (bf16): + bias + residual rows from global memory
-#pragma unroll
-    for (int pp = 0; pp < NP2; ++pp) {
-      if (128 * pp + 64 * wn >= C) continue;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = 32 * wm + 16 * i + lr;
-        const int m = min(m0 + row, p.M - 1);
-        const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)m * p.ldr0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
-          const f32x4 bb = *(const f32x4*)(p.bo + n);
-          const u32x2 rv = *(const u32x2*)(rr + n);
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc2[pp][i][j][r] + bb[r];
-          v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
-          v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
-          u32x2 pk;
-          pk[0] = pack_bf2(v[0], v[1]);
-          pk[1] = pack_bf2(v[2], v[3]);
-          *(u32x2*)panel_cell(row, n) = pk;
-        }
-      }
-    }
-    zero_acc2();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  } else {
-    if (n_issued(0) + n_issued(1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
   // ---- LayerNorm statistics of this wave's 32 rows from the resident panel -------------------------
   float rs_i[2], nm_i[2];
-  {
+  auto ln_stats = [&]() {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     const bf2 one = __builtin_bit_cast(bf2, 0x3f803f80u);
     const int row = 32 * wm + (lane & 31), half = lane >> 5;   // lanes l and l + 32 split the row's chunks
@@ -340,10 +309,328 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
       rs_i[i] = __shfl(ln_rs, 16 * i + lr, 64);
       nm_i[i] = -rs_i[i] * mu;
     }
+  };
+
+  if constexpr (!XATT) {       // (XATT: the ring's region first holds the keys / values of the attention)
+    issue(0, 0);
+    issue(1, 1);
   }
+
+  if constexpr (FRONT) {
+    // ---- h1 = r0 + fb + Wf . att1 (self-attention o-projection), q = Wq' . LayerNorm(h1) ------------------
+    // the same ring, its own 33 periods; h1 is parked in this panel's rows of `out` (this lane reads back in PRE
+    // exactly what it stores here), the queries replace it in the panel
+    constexpr int SA = KT0 * NP2, SF = SA + KT1 * NP2;
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.fw), 0, p.fw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsQ = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.qw), 0, p.qw_bytes, 0x00020000);
+    auto issue_f = [&](int s, int sl) {
+      char* dst = smem + OFF_R + sl * STG;
+      if (s < SA) {
+        const int kt = s / NP2, pp = s - kt * NP2;
+        issue_rows(rsF, dst, pp, kt * 128, KT0 * 128, C);
+      } else {
+        const int g = s - SA;
+        const int kt = g / NP2, pp = g - kt * NP2;
+        issue_rows(rsQ, dst, pp, kt * 128, C * 2, KT0 * 64);
+      }
+    };
+    int sl = 0;
+    // `landed`: step s's DMAs are known to have landed (steps SA, SA + 1: the h1 epilogue's global loads are
+    // younger and have returned; its stores may still be in flight and must not be waited for)
+    auto period_f = [&](int s, bool landed) {
+      if (s + 1 >= SF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (!landed) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    auto ahead_f = [&](int s) {
+      int sn = sl + 2; sn = sn >= NSTAGE ? sn - NSTAGE : sn;
+      if (s + 2 < SF) issue_f(s + 2, sn);
+    };
+    issue_f(0, 0);
+    issue_f(1, 1);
+    zero_acc2();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll 1
+    for (int kt = 0; kt < KT0; ++kt) {
+#pragma unroll
+      for (int pp = 0; pp < NP2; ++pp) {
+        const int s = kt * NP2 + pp;
+        period_f(s, false);
+        if (pp == 0) read_a(smem + kt * TILE);
+        ahead_f(s);
+        if (128 * pp + 64 * wn < C) mma_tile(smem + OFF_R + sl * STG, acc2[pp]);
+        sl = sl + 1 == NSTAGE ? 0 : sl + 1;
+      }
+    }
+    __builtin_amdgcn_s_barrier();                        // every wave is done with the attention rows
+    // (the global loads below drain this wave's DMA queue: steps SA, SA + 1 have landed when they return)
+#pragma unroll
+    for (int pp = 0; pp < NP2; ++pp) {
+      if (128 * pp + 64 * wn >= C) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 32 * wm + 16 * i + lr;
+        const int m = min(m0 + row, p.M - 1);
+        const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)m * p.ldr0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
+          const f32x4 bb = *(const f32x4*)(p.fb + n);
+          const u32x2 rv = *(const u32x2*)(rr + n);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc2[pp][i][j][r] + bb[r];
+          v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+          v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+          u32x2 pk;
+          pk[0] = pack_bf2(v[0], v[1]);
+          pk[1] = pack_bf2(v[2], v[3]);
+          *(u32x2*)panel_cell(row, n) = pk;
+          // rows past M: out of range, dropped -- the instruction is issued regardless
+          __builtin_amdgcn_raw_buffer_store_b64(pk, rsOut, m0 + row < p.M ? (uint32_t)(((int64_t)m * p.ldo + n) * 2) : kOOBf, 0, 0);
+        }
+      }
+    }
+    zero_acc2();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    ln_stats();
+#pragma unroll 1
+    for (int kt = 0; kt < KT1; ++kt) {
+#pragma unroll
+      for (int pp = 0; pp < NP2; ++pp) {
+        const int s = SA + kt * NP2 + pp;
+        period_f(s, kt == 0 && pp < 2);
+        if (pp == 0) read_a(smem + kt * TILE);
+        ahead_f(s);
+        mma_tile(smem + OFF_R + sl * STG, acc2[pp]);
+        sl = sl + 1 == NSTAGE ? 0 : sl + 1;
+      }
+    }
+    __builtin_amdgcn_s_barrier();                        // every wave is done with h1 (and with the ring)
+#pragma unroll
+    for (int pp = 0; pp < NP2; ++pp)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 32 * wm + 16 * i + lr;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
+          const f32x4 bb = *(const f32x4*)(p.qb + n);
+          const f32x4 cs = *(const f32x4*)(p.qcs + n);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            v[r] = __builtin_fmaf(rs_i[i], acc2[pp][i][j][r], __builtin_fmaf(nm_i[i], cs[r], bb[r]));
+          u32x2 pk;
+          pk[0] = pack_bf2(v[0], v[1]);
+          pk[1] = pack_bf2(v[2], v[3]);
+          *(u32x2*)panel_cell(row, n) = pk;
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // published by the attention phase's first barrier
+  }
+
+  if constexpr (XATT) {
+    // ---- cross-attention of the panel's 128 query rows, in place: q -> softmax(q K^T) V ----------------
+    // One key tile (Tk <= 80), so a plain softmax.  Wave (wm, wn): rows 32 wm .. +31, heads 4 wn .. +3 (48 = 40 + 8
+    // padded dims each).  16x16x16 MFMAs chain through registers: S^T = K q^T leaves lane (lr, lh) with the logits
+    // of row lr for keys 16 jk + 4 lh + r, which (exponentiated, bf16) is the B operand of O^T = V^T P^T, which
+    // leaves the lane with dims 16 jd + 4 lh + r of row lr: the very LDS cells its query fragments came from.
+    // ldm_attention_ms's layout: the logits arrive in the exp2 domain, keys carry 1 and values^T a row of ones at
+    // padded dim 40, so O[40] is the row sum of the ROUNDED probabilities.
+    // The sample's keys (80 x 768 B), then its values^T (384 x 160 B) are LDS-DMA'd into the (still idle) ring
+    // region, 16-byte chunks permuted on the source side so that the 8-byte fragment reads are conflict-free
+    // (fragments straight from global memory made this phase 17 us: 16 rows x 32 B per load instruction).
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    const int sample = m0 / p.T;
+    const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.ctx_k) + (int64_t)sample * p.Tk * (KT0 * 128), 0, (uint32_t)(p.Tk * KT0 * 128), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(p.ctx_vt) + (int64_t)sample * (KT0 * 64) * p.ldv * 2, 0, (uint32_t)(KT0 * 64 * p.ldv * 2), 0x00020000);
+    char* img = smem + OFF_R;
+#pragma unroll
+    for (int it = 0; it < XIMG / 1024 / 8 + 1; ++it) {
+      const int n = it * 8 + wave;                    // (wave-uniform)
+      if (n < XIMG / 1024) {
+        const int g = 64 * n + lane, key = g / 48, pos = g - 48 * key;
+        const int c = (pos & ~15) | ((pos ^ key) & 15);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (lds_ptr)(img + n * 1024), 16,
+                                                 key < p.Tk ? (uint32_t)(key * (KT0 * 128) + c * 16) : kOOBf, 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    u32x2 pf[4][2][5];
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      __builtin_amdgcn_sched_barrier(0);              // one head's fragments at a time (registers)
+      const int head = 4 * wn + hh;
+      u32x2 kf[5][3];
+#pragma unroll
+      for (int jk = 0; jk < 5; ++jk)
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {    // key 16 jk + lr (rows past Tk are zero), dims 16 kd + 4 lh ..
+          const int key = 16 * jk + lr, c = 6 * head + 2 * kd + (lh >> 1);
+          kf[jk][kd] = *(const u32x2*)(img + key * (KT0 * 128) + (((c & ~15) | ((c ^ key) & 15)) << 4) + (lh & 1) * 8);
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 32 * wm + 16 * i + lr;
+        u32x2 qf[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) {
+          const int n = 48 * head + 16 * kd + 4 * lh;
+          qf[kd] = *(const u32x2*)(smem + (n >> 6) * TILE + row * 128 + ((((n & 63) >> 3) ^ ((row >> 1) & 7)) << 4) + (n & 7) * 2);
+        }
+        f32x4 sc[5];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jk = 0; jk < 5; ++jk) {
+          sc[jk] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd)
+            sc[jk] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, kf[jk][kd]),
+                                                               __builtin_bit_cast(s16x4, qf[kd]), sc[jk], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (16 * jk + 4 * lh + r >= p.Tk) sc[jk][r] = -INFINITY;
+            mx = fmaxf(mx, sc[jk][r]);
+          }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#pragma unroll
+        for (int jk = 0; jk < 5; ++jk) {
+          pf[hh][i][jk][0] = pack_bf2(__builtin_amdgcn_exp2f(sc[jk][0] - mx), __builtin_amdgcn_exp2f(sc[jk][1] - mx));
+          pf[hh][i][jk][1] = pack_bf2(__builtin_amdgcn_exp2f(sc[jk][2] - mx), __builtin_amdgcn_exp2f(sc[jk][3] - mx));
+          // (pinned here: the compiler otherwise sinks all 640 exponentials below the barrier, next to their use,
+          // and keeps every logit alive until then)
+          asm volatile("" : "+v"(pf[hh][i][jk][0]), "+v"(pf[hh][i][jk][1]));
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();                     // every wave is done with the keys
+#pragma unroll
+    for (int it = 0; it < XIMG / 1024 / 8 + 1; ++it) {
+      const int n = it * 8 + wave;
+      if (n < XIMG / 1024) {
+        const int g = 64 * n + lane, dim = g / 10, pos = g - 10 * dim;
+        const int c = pos ^ ((dim >> 3) & 1);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsV, (lds_ptr)(img + n * 1024), 16,
+                                                 (uint32_t)(dim * p.ldv * 2 + c * 16), 0, 0, 0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int head = 4 * wn + hh;
+      u32x2 vf[3][5];
+#pragma unroll
+      for (int jd = 0; jd < 3; ++jd)
+#pragma unroll
+        for (int jk = 0; jk < 5; ++jk) {    // dim 16 jd + lr, keys 16 jk + 4 lh ..; pad keys masked (may hold anything)
+          const int dim = 48 * head + 16 * jd + lr, c = (2 * jk + (lh >> 1)) ^ ((dim >> 3) & 1);
+          u32x2 v = *(const u32x2*)(img + dim * 160 + c * 16 + (lh & 1) * 8);
+          const int k0 = 16 * jk + 4 * lh;
+          if (k0 + 1 >= p.Tk) v[0] &= (k0 < p.Tk) ? 0x0000ffffu : 0u;
+          if (k0 + 3 >= p.Tk) v[1] &= (k0 + 2 < p.Tk) ? 0x0000ffffu : 0u;
+          vf[jd][jk] = v;
+        }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 32 * wm + 16 * i + lr;
+        f32x4 o[3];
+#pragma unroll
+        for (int jd = 0; jd < 3; ++jd) {
+          o[jd] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jk = 0; jk < 5; ++jk)
+            o[jd] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vf[jd][jk]),
+                                                              __builtin_bit_cast(s16x4, pf[hh][i][jk]), o[jd], 0, 0, 0);
+        }
+        // row sum: dim 40 = block 2, lh = 2, r = 0
+        const float inv = __builtin_amdgcn_rcpf(__shfl(o[2][0], 32 + lr, 64));
+#pragma unroll
+        for (int jd = 0; jd < 3; ++jd) {
+          u32x2 pk;
+          pk[0] = pack_bf2(o[jd][0] * inv, o[jd][1] * inv);
+          pk[1] = pack_bf2(o[jd][2] * inv, o[jd][3] * inv);
+          if (jd == 2 && lh >= 2) pk = u32x2{0u, 0u};      // padded dims 40 .. 47
+          const int n = 48 * head + 16 * jd + 4 * lh;
+          *(u32x2*)(smem + (n >> 6) * TILE + row * 128 + ((((n & 63) >> 3) ^ ((row >> 1) & 7)) << 4) + (n & 7) * 2) = pk;
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                     // the values^T image is free: the ring starts
+    issue(0, 0);
+    issue(1, 1);
+  }
+
+  zero_acc2();
+
+  // ---- PRE: h = r0 + bo + Wo . att ------------------------------------------------------------------
+  if constexpr (PRE) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the panel's DMAs are older than the two weight tiles
+#pragma unroll 1
+    for (int kt = 0; kt < KT0; ++kt) {
+#pragma unroll
+      for (int pp = 0; pp < NP2; ++pp) {
+        const int s = kt * NP2 + pp;
+        begin_period(s, false);                          // (XATT: the lgkmcnt(0) above precedes the first barrier)
+        if (pp == 0) read_a(smem + kt * TILE);           // attention rows (visible after the first barrier)
+        issue_ahead(s);
+        if (128 * pp + 64 * wn < C) mma_tile(smem + OFF_R + slot * STG, acc2[pp]);
+        next_slot();
+      }
+    }
+    __builtin_amdgcn_s_barrier();                        // every wave is done with the attention rows
+    // h -> the panel (bf16): + bias + residual rows from global memory
+#pragma unroll
+    for (int pp = 0; pp < NP2; ++pp) {
+      if (128 * pp + 64 * wn >= C) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = 32 * wm + 16 * i + lr;
+        const int m = min(m0 + row, p.M - 1);
+        const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)m * p.ldr0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
+          const f32x4 bb = *(const f32x4*)(p.bo + n);
+          u32x2 rv;
+          if constexpr (FRONT)
+            rv = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsOut, (uint32_t)(((int64_t)m * p.ldo + n) * 2), 0, 0));
+          else rv = *(const u32x2*)(rr + n);
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc2[pp][i][j][r] + bb[r];
+          v[0] += __uint_as_float(rv[0] << 16); v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+          v[2] += __uint_as_float(rv[1] << 16); v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+          u32x2 pk;
+          pk[0] = pack_bf2(v[0], v[1]);
+          pk[1] = pack_bf2(v[2], v[3]);
+          *(u32x2*)panel_cell(row, n) = pk;
+        }
+      }
+    }
+    zero_acc2();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    if (n_issued(0) + n_issued(1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  ln_stats();
 
   // ---- feed-forward: per hidden chunk 5 periods of W1 (-> GEGLU -> hidden tile) and 3 of W2 -----------
   // (the u loop is unrolled: the period's role and the accumulator piece are compile-time per instance)
+#pragma unroll 1
   for (int c = 0; c < NCH; ++c) {
 #pragma unroll
     for (int u = 0; u < SPC; ++u) {
@@ -428,6 +715,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     }
     zero_acc2();
     // ---- POST: out = r1 + bp + Wp . y ---------------------------------------------------------------
+#pragma unroll 1
     for (int kt = 0; kt < KT1; ++kt) {
 #pragma unroll
       for (int pp = 0; pp < NP2; ++pp) {
@@ -515,7 +803,7 @@ extern "C" int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const f
   FfnArgs a;
   fill_common(&a, x, ldx, w1, aux, w2, b2, out, ldo, M, C, C, eps);
   dim3 grid((M + 127) / 128);
-  hipLaunchKernelGGL((st_tail_kernel<320, 0, false>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((st_tail_kernel<320, 0, 0>), grid, dim3(512), 0, (hipStream_t)stream, a);
   return ldm_launch_status("ldm_ffn_geglu");
 }
 
@@ -535,6 +823,64 @@ extern "C" int ldm_st_tail(const void* att, int64_t lda, int K0, const void* wo,
   a.wo = (const char*)wo; a.bo = bo; a.r0 = (const char*)r0; a.ldr0 = ldr0; a.wo_bytes = (uint32_t)(C * K0 * 2);
   a.wp = (const char*)wp; a.bp = bp; a.r1 = (const char*)r1; a.ldr1 = ldr1; a.wp_bytes = (uint32_t)(C * C * 2);
   dim3 grid((M + 127) / 128);
-  hipLaunchKernelGGL((st_tail_kernel<320, 6, true>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((st_tail_kernel<320, 6, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
   return ldm_launch_status("ldm_st_tail");
+}
+
+extern "C" int ldm_st_xtail(const void* q, int64_t ldq, int K0, const void* ctx_k, const void* ctx_vt, int Tk, int ldv,
+                            int T, const void* wo, const float* bo, const void* r0, int64_t ldr0, const void* w1,
+                            const float* aux, const void* w2, const float* b2, const void* wp, const float* bp,
+                            const void* r1, int64_t ldr1, void* out, int64_t ldo, int M, int C, float eps, int dtype,
+                            void* stream) {
+  int st = check_common("ldm_st_xtail", q, ldq, w1, aux, w2, b2, out, ldo, M, C, K0, eps, dtype);
+  if (st) return st;
+  LDM_CHECK_ARG(K0 == 384, "ldm_st_xtail: attention width K0 = 384 (8 heads of 40 padded to 48) only, got %d", K0);
+  LDM_CHECK_ARG(wo && bo && r0 && wp && bp && r1 && ctx_k && ctx_vt, "ldm_st_xtail: null pointer");
+  LDM_CHECK_ARG(Tk >= 1 && Tk <= 80 && ldv >= 80 && ldv % 4 == 0 && T > 0 && T % 128 == 0 && M % T == 0,
+                "ldm_st_xtail: needs Tk <= 80 keys (V^T rows of >= 80), query rows per sample a multiple of 128 "
+                "(Tk=%d ldv=%d T=%d M=%d)", Tk, ldv, T, M);
+  auto al16 = [](const void* x) { return ((uintptr_t)x % 16) == 0; };
+  LDM_CHECK_ARG(al16(wo) && al16(bo) && al16(wp) && al16(bp) && ((uintptr_t)r0 % 8) == 0 && ((uintptr_t)r1 % 8) == 0 &&
+                    al16(ctx_k) && al16(ctx_vt) && ldv % 8 == 0 && ldr0 % 4 == 0 && ldr1 % 4 == 0 &&
+                    ldr0 >= C && ldr1 >= C, "ldm_st_xtail: alignment / residual strides");
+  FfnArgs a;
+  fill_common(&a, q, ldq, w1, aux, w2, b2, out, ldo, M, C, K0, eps);
+  a.wo = (const char*)wo; a.bo = bo; a.r0 = (const char*)r0; a.ldr0 = ldr0; a.wo_bytes = (uint32_t)(C * K0 * 2);
+  a.wp = (const char*)wp; a.bp = bp; a.r1 = (const char*)r1; a.ldr1 = ldr1; a.wp_bytes = (uint32_t)(C * C * 2);
+  a.ctx_k = (const char*)ctx_k; a.ctx_vt = (const char*)ctx_vt; a.Tk = Tk; a.ldv = ldv; a.T = T;
+  dim3 grid((M + 127) / 128);
+  hipLaunchKernelGGL((st_tail_kernel<320, 6, 3>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  return ldm_launch_status("ldm_st_xtail");
+}
+
+extern "C" int ldm_st_block(const void* att, int64_t lda, int K0, const void* wo1, const float* bo1, const void* r0,
+                            int64_t ldr0, const void* wq, const float* qcs, const float* qb, const void* ctx_k,
+                            const void* ctx_vt, int Tk, int ldv, int T, const void* wo2, const float* bo2,
+                            const void* w1, const float* aux, const void* w2, const float* b2, const void* wp,
+                            const float* bp, const void* r1, int64_t ldr1, void* out, int64_t ldo, int M, int C,
+                            float eps, int dtype, void* stream) {
+  int st = check_common("ldm_st_block", att, lda, w1, aux, w2, b2, out, ldo, M, C, K0, eps, dtype);
+  if (st) return st;
+  LDM_CHECK_ARG(K0 == 384, "ldm_st_block: attention width K0 = 384 (8 heads of 40 padded to 48) only, got %d", K0);
+  LDM_CHECK_ARG(wo1 && bo1 && r0 && wq && qcs && qb && wo2 && bo2 && wp && bp && r1 && ctx_k && ctx_vt, "ldm_st_block: null pointer");
+  LDM_CHECK_ARG(Tk >= 1 && Tk <= 80 && ldv >= 80 && ldv % 8 == 0 && T > 0 && T % 128 == 0 && M % T == 0,
+                "ldm_st_block: needs Tk <= 80 keys (V^T rows of >= 80), query rows per sample a multiple of 128 "
+                "(Tk=%d ldv=%d T=%d M=%d)", Tk, ldv, T, M);
+  auto al16 = [](const void* x) { return ((uintptr_t)x % 16) == 0; };
+  LDM_CHECK_ARG(al16(wo1) && al16(bo1) && al16(wq) && al16(qcs) && al16(qb) && al16(wo2) && al16(bo2) && al16(wp) &&
+                    al16(bp) && al16(ctx_k) && al16(ctx_vt) && ((uintptr_t)r0 % 8) == 0 && ((uintptr_t)r1 % 8) == 0 &&
+                    ldr0 % 4 == 0 && ldr1 % 4 == 0 && ldr0 >= C && ldr1 >= C, "ldm_st_block: alignment / residual strides");
+  LDM_CHECK_ARG((((int64_t)M - 1) * ldo + C) * 2 < (1ll << 31), "ldm_st_block: output extent must be < 2 GiB");
+  LDM_CHECK_ARG(out != r0 && out != r1 && out != att, "ldm_st_block: out is also scratch, it must not alias an input");
+  FfnArgs a;
+  fill_common(&a, att, lda, w1, aux, w2, b2, out, ldo, M, C, K0, eps);
+  a.fw = (const char*)wo1; a.fb = bo1; a.r0 = (const char*)r0; a.ldr0 = ldr0; a.fw_bytes = (uint32_t)(C * K0 * 2);
+  a.qw = (const char*)wq; a.qcs = qcs; a.qb = qb; a.qw_bytes = (uint32_t)(K0 * C * 2);
+  a.out_bytes = (uint32_t)((((int64_t)M - 1) * ldo + C) * 2);
+  a.wo = (const char*)wo2; a.bo = bo2; a.wo_bytes = (uint32_t)(C * K0 * 2);
+  a.wp = (const char*)wp; a.bp = bp; a.r1 = (const char*)r1; a.ldr1 = ldr1; a.wp_bytes = (uint32_t)(C * C * 2);
+  a.ctx_k = (const char*)ctx_k; a.ctx_vt = (const char*)ctx_vt; a.Tk = Tk; a.ldv = ldv; a.T = T;
+  dim3 grid((M + 127) / 128);
+  hipLaunchKernelGGL((st_tail_kernel<320, 6, 4>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  return ldm_launch_status("ldm_st_block");
 }

@@ -722,6 +722,48 @@ def st_tail(att, wo, bo, r0, w1, aux, w2, b2, wp, bp, r1, out, eps):
   return out
 
 
+def st_xtail(q, ctx_k, ctx_vt, wo, bo, r0, w1, aux, w2, b2, wp, bp, r1, out, eps):
+  """st_tail with the cross-attention in front: q [R, T, 384] are the queries, ctx_k [R, Tk, 384] / ctx_vt
+  [R, 384, ld] the context keys / values^T, all in the matrix-side-softmax layout of ops.attention(...,
+  matrix_softmax=True); the attention output lives only in LDS (ldm_st_xtail)."""
+  Cc, K0 = out.shape[-1], q.shape[-1]
+  R, T = q.shape[0], q.shape[1]
+  M = R * T
+  assert q.dim() == 3 and q.is_contiguous() and ctx_k.is_contiguous() and ctx_vt.is_contiguous()
+  assert ctx_k.shape[0] == R and ctx_k.shape[2] == K0 and tuple(ctx_vt.shape[:2]) == (R, K0)
+  assert out.numel() // Cc == M and q.dtype == out.dtype == r0.dtype == r1.dtype == ctx_k.dtype == ctx_vt.dtype
+  assert tuple(wo.shape) == (Cc, K0) and tuple(wp.shape) == (Cc, Cc) and wo.is_contiguous() and wp.is_contiguous()
+  assert tuple(w1.shape) == (8 * Cc, Cc) and tuple(w2.shape) == (Cc, 4 * Cc) and w1.is_contiguous() and w2.is_contiguous()
+  assert aux.dtype == torch.float32 and aux.numel() == 8 * Cc * 2 and aux.is_contiguous()
+  check(lib.ldm_st_xtail(_ptr(q), K0, K0, _ptr(ctx_k), _ptr(ctx_vt), ctx_k.shape[1], ctx_vt.shape[2], T, _ptr(wo),
+                         _ptr(_f32(bo, "bo")), _ptr(r0), row_ld(r0), _ptr(w1), _ptr(aux), _ptr(w2), _ptr(_f32(b2, "b2")),
+                         _ptr(wp), _ptr(_f32(bp, "bp")), _ptr(r1), row_ld(r1), _ptr(out), row_ld(out), M, Cc, float(eps),
+                         code(out.dtype), _stream()), "ldm_st_xtail")
+  return out
+
+
+def st_block(att, wo1, bo1, r0, wq, qcs, qb, ctx_k, ctx_vt, wo2, bo2, w1, aux, w2, b2, wp, bp, r1, out, eps):
+  """From the self-attention's output to the SpatialTransformer's output in ONE launch (ldm_st_block): o-projection
+  + residual r0, LayerNorm-folded query projection, cross-attention against ctx_k / ctx_vt, o-projection + residual,
+  feed-forward, proj_out + residual r1.  att [R, T, 384]; layouts as st_xtail / linear(ln_fold=...)."""
+  Cc, K0 = out.shape[-1], att.shape[-1]
+  R, T = att.shape[0], att.shape[1]
+  M = R * T
+  assert att.dim() == 3 and att.is_contiguous() and ctx_k.is_contiguous() and ctx_vt.is_contiguous()
+  assert ctx_k.shape[0] == R and ctx_k.shape[2] == K0 and tuple(ctx_vt.shape[:2]) == (R, K0)
+  assert out.numel() // Cc == M and att.dtype == out.dtype == r0.dtype == r1.dtype == ctx_k.dtype == ctx_vt.dtype
+  for w_, shp in ((wo1, (Cc, K0)), (wq, (K0, Cc)), (wo2, (Cc, K0)), (wp, (Cc, Cc)), (w1, (8 * Cc, Cc)), (w2, (Cc, 4 * Cc))):
+    assert tuple(w_.shape) == shp and w_.is_contiguous() and w_.dtype == out.dtype
+  assert aux.dtype == torch.float32 and aux.numel() == 8 * Cc * 2 and aux.is_contiguous()
+  assert qcs.dtype == torch.float32 and qcs.numel() == K0
+  check(lib.ldm_st_block(_ptr(att), K0, K0, _ptr(wo1), _ptr(_f32(bo1, "bo1")), _ptr(r0), row_ld(r0), _ptr(wq), _ptr(qcs),
+                         _ptr(_f32(qb, "qb")), _ptr(ctx_k), _ptr(ctx_vt), ctx_k.shape[1], ctx_vt.shape[2], T, _ptr(wo2),
+                         _ptr(_f32(bo2, "bo2")), _ptr(w1), _ptr(aux), _ptr(w2), _ptr(_f32(b2, "b2")), _ptr(wp),
+                         _ptr(_f32(bp, "bp")), _ptr(r1), row_ld(r1), _ptr(out), row_ld(out), M, Cc, float(eps),
+                         code(out.dtype), _stream()), "ldm_st_block")
+  return out
+
+
 def time_embedding(out, channels, t_rows=None, steps=None, index=None):
   rows = out.shape[0]
   check(lib.ldm_time_embedding(_ptr(t_rows), _ptr(steps), _ptr(index), _ptr(_f32(out, "out")), rows,

@@ -123,7 +123,7 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True):
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -151,6 +151,8 @@ class UNet:
     self._matrix_softmax = bool(matrix_softmax)   # ldm_attention_ms on the 40-wide heads (with the fold; A/B: False)
     self._fused_ffn = bool(fused_ffn)             # ldm_ffn_geglu on the C = 320 blocks (needs the fold; A/B: False)
     self._fused_tail = bool(fused_tail)           # ... with the o-projection before and proj_out after it (ldm_st_tail)
+    self._fused_block = bool(fused_block)         # ... and o1-projection + query projection in front (ldm_st_block)
+    self._fused_xattn = bool(fused_xattn)         # ... and the cross-attention in front of the tail (ldm_st_xtail)
     self._ffn_min_rows = int(ffn_min_rows)        # ... from 192 panels of 128 rows on (3/4 of the CUs busy)
     self._gn_single = bool(gn_single_launch)      # False: partial-sums + apply launches everywhere (A/B)
     self._defer_reduce = bool(defer_reduce)   # split-K reduces fused into the consuming GroupNorm (A/B: False)
@@ -385,17 +387,30 @@ class UNet:
     ms = fold is not None and st.ms
     ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
     hb = B_.get("st_b", (R, T, c), dt)
+    q = B_.get("st_q", (R, T, hs), dt)
+    panel = (fold is not None and st.ffn_aux is not None and self._fused_ffn and R * T >= self._ffn_min_rows)
+    xtail = (panel and self._fused_tail and self._fused_xattn and ms and hs == 384 and T % 128 == 0
+             and st.ctx_k.shape[1] <= 80 and st.ctx_vt.shape[2] >= 80)
+    if xtail and self._fused_block:
+      # everything from the self-attention's output to the block's output: ONE row-panel launch (ldm_st_block)
+      ops.st_block(att, st.o1[0], st.o1[1], ha, fold["q2"][0], fold["q2"][1], fold["q2"][2], st.ctx_k, st.ctx_vt,
+                   st.o2[0], st.o2[1], fold["geglu"][0], st.ffn_aux, st.ff_out[0], st.ff_out[1], st.proj_out[0],
+                   st.proj_out[1], x, out, LN_EPS)
+      return out
     ops.linear(att, st.o1[0], hb, bias=st.o1[1], residual=ha, ln=lnp(1))
     # cross-attention (unet.py:311-312)
-    q = B_.get("st_q", (R, T, hs), dt)
     if fold is not None:
       ops.linear(hb, fold["q2"][0], q, bias=fold["q2"][2], ln_fold=(fold["q2"][1], LN_EPS))
     else:
       if not fuse_ln:
         ops.layernorm(hb, st.ln[1][0], st.ln[1][1], ln, LN_EPS)
       ops.linear(ln, st.q2, q)
+    if xtail:
+      # ... with the cross-attention itself in front of it, in place in the LDS panel
+      ops.st_xtail(q, st.ctx_k, st.ctx_vt, st.o2[0], st.o2[1], hb, fold["geglu"][0], st.ffn_aux, st.ff_out[0],
+                   st.ff_out[1], st.proj_out[0], st.proj_out[1], x, out, LN_EPS)
+      return out
     ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
-    panel = (fold is not None and st.ffn_aux is not None and self._fused_ffn and R * T >= self._ffn_min_rows)
     if panel and self._fused_tail and hs == 384:
       # o-projection + residual, LayerNorm -> GEGLU -> FF-out + residual, proj_out + residual: ONE row-panel
       # launch; the two intermediate residual-stream tensors live only in LDS (unet.py:312-313, :363-365)

@@ -349,10 +349,121 @@ def test_st_tail_row_panel_kernel(dev, M):
   assert r < 5e-3 and r <= r4 * 1.2 + 1e-4 and d < 5e-3
 
 
-@pytest.mark.parametrize("fused,tail", [(True, True), (True, False), (False, False)])
-def test_unet_fused_ffn_matches_the_unfused_unet(dev, fused, tail):
-  """A C = 320 U-Net level through ldm_st_tail / ldm_ffn_geglu (ffn_min_rows=1) against the oracle and the unfused
-  launches."""
+@pytest.mark.parametrize("R,T,Tk,nan_pads", [(2, 128, 77, True), (3, 256, 77, False), (1, 384, 80, False), (2, 128, 5, True)])
+def test_st_xtail_cross_attention_in_the_panel(dev, R, T, Tk, nan_pads):
+  """Cross-attention (unet.py:273-291) + o-projection + feed-forward + proj_out as ONE launch: against the oracle
+  and against ldm_attention_ms followed by ldm_st_tail on the same operands."""
+  o = ops()
+  C, H, S, sp = 320, 8, 40, 48
+  K0, M = H * sp, R * T
+  scale = S ** -0.5
+  qb, kb, vb = (rnd(sh, sd).to(BF) for sh, sd in (((R, T, H, S), 100), ((R, Tk, H, S), 101), ((R, Tk, H, S), 102)))
+  qb = qb * 2.0
+  logits = torch.einsum("nqhs,nchs->nhqc", qb.float(), kb.float()) * scale
+  att_ref = torch.einsum("nhqc,nchs->nqhs", torch.softmax(logits, dim=3), vb.float())
+  qd = torch.zeros(R, T, H, sp); qd[..., :S] = qb.float() * (scale * L.MS_LOG2E)
+  kd = torch.zeros(R, Tk, H, sp); kd[..., :S] = kb.float(); kd[..., L.MS_DIM] = 1.0
+  ld = 80 if Tk > 8 else 88
+  vt = torch.full((R, K0, ld), float("nan") if nan_pads else 0.0)
+  vv = torch.zeros(R, Tk, H, sp); vv[..., :S] = vb.float(); vv[..., L.MS_DIM] = 1.0
+  vt[:, :, :Tk] = vv.reshape(R, Tk, K0).permute(0, 2, 1)
+  qd, kd, vt = qd.reshape(R, T, K0).to(BF).to(dev), kd.reshape(R, Tk, K0).to(BF).to(dev), vt.to(BF).to(dev)
+  r0, gamma, beta = _ln_case(M, C, 103, 2.0)
+  r0b, r1b = r0.to(BF), rnd((M, C), 104).to(BF)
+  ko = torch.zeros(K0, C)                                    # rows of the padded dims are zero (layout.merge_kernel)
+  ko.view(H, sp, C)[:, :S] = rnd((H, S, C), 105, (H * S) ** -0.5)
+  bo, b2, bp = rnd((C,), 106), rnd((C,), 107), rnd((C,), 108)
+  k1 = rnd((C, 8 * C), 109, C ** -0.5).numpy()
+  b1 = rnd((8 * C,), 110).numpy()
+  k2 = rnd((4 * C, C), 111, (4 * C) ** -0.5).numpy()
+  kp = rnd((C, C), 112, C ** -0.5).numpy()
+  att_p = torch.zeros(R, T, H, sp); att_p[..., :S] = att_ref
+  h = r0b.float() + O.dense(att_p.reshape(M, K0), ko, bo)
+  y = O.dense(O.layer_norm(h, gamma, beta, eps=1e-5), torch.from_numpy(k1), torch.from_numpy(b1))
+  y = h + O.dense(y[:, :4 * C] * O.gelu(y[:, 4 * C:]), torch.from_numpy(k2), b2)
+  ref = r1b.float() + O.dense(y, torch.from_numpy(kp), bp)
+  gw, gb = L.geglu_kernel(k1, b1, torch.float32, "cpu")
+  w1, cs, bb = L.ln_fold(gw, gamma.numpy(), beta.numpy(), gb.numpy(), BF, dev)
+  wo, w2, wp = (L.dense_kernel(k, BF, dev) for k in (ko.numpy(), k2, kp))
+  aux = L.ffn_aux(cs, bb)
+  r0d, r1d = r0b.to(dev), r1b.to(dev)
+  out = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+  o.st_xtail(qd, kd, vt, wo, bo.to(dev), r0d, w1, aux, w2, b2.to(dev), wp, bp.to(dev), r1d, out, 1e-5)
+  att = torch.empty(R, T, K0, dtype=BF, device=dev)
+  o.attention(qd, kd, vt, att, H, sp, scale, matrix_softmax=True)
+  out2 = torch.empty(M, C, dtype=BF, device=dev)
+  o.st_tail(att, wo, bo.to(dev), r0d, w1, aux, w2, b2.to(dev), wp, bp.to(dev), r1d, out2, 1e-5)
+  r, r2, d = rel(out, ref), rel(out2, ref), rel(out, out2.float().cpu())
+  print(f"st_xtail R={R} T={T} Tk={Tk}: rel {r:.3e} (attention + st_tail {r2:.3e}; fused vs those {d:.3e})")
+  assert torch.isfinite(out.float()).all()
+  assert r < 5e-3 and r <= r2 * 1.2 + 1e-4 and d < 5e-3
+
+
+@pytest.mark.parametrize("R,T,Tk", [(2, 128, 77), (2, 384, 77), (1, 256, 9)])
+def test_st_block_from_self_attention_output_to_block_output(dev, R, T, Tk):
+  """o-projection + residual, LayerNorm-folded query projection, cross-attention, o-projection + residual,
+  feed-forward, proj_out + residual (unet.py:310-313, :363-365) as ONE launch: against the oracle and against the
+  launches it replaces (two GEMMs, then ldm_st_xtail)."""
+  o = ops()
+  C, H, S, sp = 320, 8, 40, 48
+  K0, M = H * sp, R * T
+  scale = S ** -0.5
+  att1 = rnd((M, K0), 120).to(BF)
+  r0, gamma, beta = _ln_case(M, C, 121, 2.0)
+  r0b, r1b = r0.to(BF), rnd((M, C), 122).to(BF)
+  g2, be2 = 1.0 + 0.3 * rnd((C,), 123), 0.2 * rnd((C,), 124)
+  ko1 = rnd((K0, C), 125, K0 ** -0.5)
+  bo1, bo2, b2, bp = (rnd((C,), sd) for sd in (126, 127, 128, 129))
+  kq = rnd((C, H, S), 130, C ** -0.5)                        # the query projection has no bias (unet.py:262)
+  kb, vb = rnd((R, Tk, H, S), 131).to(BF), rnd((R, Tk, H, S), 132).to(BF)
+  ko2 = torch.zeros(K0, C)
+  ko2.view(H, sp, C)[:, :S] = rnd((H, S, C), 133, (H * S) ** -0.5)
+  k1 = rnd((C, 8 * C), 134, C ** -0.5).numpy()
+  b1 = rnd((8 * C,), 135).numpy()
+  k2 = rnd((4 * C, C), 136, (4 * C) ** -0.5).numpy()
+  kp = rnd((C, C), 137, C ** -0.5).numpy()
+  # oracle
+  h1 = r0b.float() + O.dense(att1.float(), ko1, bo1)
+  qr = torch.einsum("mc,chs->mhs", O.layer_norm(h1, g2, be2, eps=1e-5), kq).reshape(R, T, H, S)
+  logits = torch.einsum("nqhs,nchs->nhqc", qr, kb.float()) * scale
+  a2 = torch.einsum("nhqc,nchs->nqhs", torch.softmax(logits, dim=3), vb.float())
+  a2p = torch.zeros(R, T, H, sp); a2p[..., :S] = a2
+  h2 = h1 + O.dense(a2p.reshape(M, K0), ko2, bo2)
+  y = O.dense(O.layer_norm(h2, gamma, beta, eps=1e-5), torch.from_numpy(k1), torch.from_numpy(b1))
+  y = h2 + O.dense(y[:, :4 * C] * O.gelu(y[:, 4 * C:]), torch.from_numpy(k2), b2)
+  ref = r1b.float() + O.dense(y, torch.from_numpy(kp), bp)
+  # device operands
+  wq_nk = torch.zeros(H, sp, C); wq_nk[:, :S] = kq.permute(1, 2, 0) * (scale * L.MS_LOG2E)
+  wq, qcs, qb = L.ln_fold(wq_nk.reshape(K0, C), g2.numpy(), be2.numpy(), None, BF, dev)
+  kd = torch.zeros(R, Tk, H, sp); kd[..., :S] = kb.float(); kd[..., L.MS_DIM] = 1.0
+  vt = torch.full((R, K0, 80), float("nan"))
+  vv = torch.zeros(R, Tk, H, sp); vv[..., :S] = vb.float(); vv[..., L.MS_DIM] = 1.0
+  vt[:, :, :Tk] = vv.reshape(R, Tk, K0).permute(0, 2, 1)
+  kd, vt = kd.reshape(R, Tk, K0).to(BF).to(dev), vt.to(BF).to(dev)
+  gw, gb = L.geglu_kernel(k1, b1, torch.float32, "cpu")
+  w1, cs, bb = L.ln_fold(gw, gamma.numpy(), beta.numpy(), gb.numpy(), BF, dev)
+  wo1, wo2, w2, wp = (L.dense_kernel(k, BF, dev) for k in (ko1.numpy(), ko2.numpy(), k2, kp))
+  aux = L.ffn_aux(cs, bb)
+  ad, r0d, r1d = att1.reshape(R, T, K0).to(dev), r0b.to(dev), r1b.to(dev)
+  bo1d, bo2d, b2d, bpd = (t_.to(dev) for t_ in (bo1, bo2, b2, bp))
+  out = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+  o.st_block(ad, wo1, bo1d, r0d, wq, qcs, qb, kd, vt, wo2, bo2d, w1, aux, w2, b2d, wp, bpd, r1d, out, 1e-5)
+  hd = torch.empty(M, C, dtype=BF, device=dev)
+  o.linear(ad.view(M, K0), wo1, hd, bias=bo1d, residual=r0d)
+  qd = torch.empty(R, T, K0, dtype=BF, device=dev)
+  o.linear(hd, wq, qd.view(M, K0), bias=qb, ln_fold=(qcs, 1e-5))
+  out2 = torch.empty(M, C, dtype=BF, device=dev)
+  o.st_xtail(qd, kd, vt, wo2, bo2d, hd, w1, aux, w2, b2d, wp, bpd, r1d, out2, 1e-5)
+  r, r2, d = rel(out, ref), rel(out2, ref), rel(out, out2.float().cpu())
+  print(f"st_block R={R} T={T} Tk={Tk}: rel {r:.3e} (2 GEMMs + st_xtail {r2:.3e}; fused vs those {d:.3e})")
+  assert torch.isfinite(out.float()).all()
+  assert r < 6e-3 and r <= r2 * 1.2 + 1e-4 and d < 3e-3
+
+
+@pytest.mark.parametrize("fused,tail,block", [(True, True, True), (True, True, False), (True, False, False), (False, False, False)])
+def test_unet_fused_ffn_matches_the_unfused_unet(dev, fused, tail, block):
+  """A C = 320 U-Net level through ldm_st_block / ldm_st_xtail / ldm_ffn_geglu (ffn_min_rows=1) against the oracle
+  and the unfused launches."""
   from ldm_tf2_amd.unet import UNet
   cfg = dict(model_channels=320, out_channels=4, num_blocks=1, channel_mult=(1,), num_heads=8)
   ctx_dim = 128
@@ -365,9 +476,9 @@ def test_unet_fused_ffn_matches_the_unfused_unet(dev, fused, tail):
   base = UNet(**cfg, weights=w, dtype=BF, device=dev, context_dim=ctx_dim, fold_min_rows=1, fused_ffn=False)
   out0 = base(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
   unet = UNet(**cfg, weights=w, dtype=BF, device=dev, context_dim=ctx_dim, fold_min_rows=1, fused_ffn=fused,
-              fused_tail=tail, ffn_min_rows=1)
+              fused_tail=tail, fused_block=block, ffn_min_rows=1)
   assert unet.sts[0].ffn_aux is not None and unet.sts[0].ms
-  calls = {"ldm_ffn_geglu": 0, "ldm_st_tail": 0}
+  calls = {"ldm_ffn_geglu": 0, "ldm_st_tail": 0, "ldm_st_xtail": 0, "ldm_st_block": 0}
   origs = {k: getattr(ops().lib, k) for k in calls}
   for k in calls:
     def counted(*a, _orig=origs[k], _k=k):
@@ -379,6 +490,8 @@ def test_unet_fused_ffn_matches_the_unfused_unet(dev, fused, tail):
   finally:
     for k in calls:
       setattr(ops().lib, k, origs[k])
-  assert (calls["ldm_st_tail"] > 0) == (fused and tail) and (calls["ldm_ffn_geglu"] > 0) == (fused and not tail)
-  print(f"C=320 U-Net, fused feed-forward={fused} tail={tail}: rel {rel(out, ref):.3e} (unfused {rel(out0, ref):.3e}; {calls})")
+  assert (calls["ldm_st_block"] > 0) == (fused and tail and block)
+  assert (calls["ldm_st_xtail"] > 0) == (fused and tail and not block)
+  assert (calls["ldm_ffn_geglu"] > 0) == (fused and not tail) and calls["ldm_st_tail"] == 0
+  print(f"C=320 U-Net, fused feed-forward={fused} tail={tail} block={block}: rel {rel(out, ref):.3e} (unfused {rel(out0, ref):.3e}; {calls})")
   assert rel(out, ref) < 4e-2 and rel(out, ref) <= rel(out0, ref) * 1.5

@@ -56,3 +56,33 @@ for M in [int(a) for a in sys.argv[1:]] or [32768, 16384]:
   t_4 = time_fn(four, 5)
   gf += 2.0 * M * C * (384 + C) * 1e-9
   print(f"      st_tail (o-projection + feed-forward + proj_out): {t_t * 1e3:7.1f} us ({gf / t_t:5.0f} TFLOP/s)   four launches {t_4 * 1e3:7.1f} us")
+  if M % 1024 == 0:
+    R = M // 1024
+    qx = torch.randn(R, 1024, 384, device=dev).to(torch.bfloat16)
+    ck = torch.randn(R, 77, 384, device=dev).to(torch.bfloat16)
+    cv = torch.randn(R, 384, 80, device=dev).to(torch.bfloat16)
+    for t_ in (qx.view(R, 1024, 8, 48), ck.view(R, 77, 8, 48)):
+      t_[..., 40:] = 0
+    ck.view(R, 77, 8, 48)[..., 40] = 1
+    cv.view(R, 8, 48, 80)[:, :, 40:, :] = 0
+    cv.view(R, 8, 48, 80)[:, :, 40, :] = 1
+    a2 = torch.empty_like(qx)
+    t_x = time_fn(lambda: ops.st_xtail(qx, ck, cv, wo, b2, x, w1, aux, w2, b2, wp, b2, r1, out, 1e-5), 5)
+
+    def att_tail():
+      ops.attention(qx, ck, cv, a2, 8, 48, 40 ** -0.5, matrix_softmax=True)
+      ops.st_tail(a2, wo, b2, x, w1, aux, w2, b2, wp, b2, r1, out, 1e-5)
+
+    t_x2 = time_fn(att_tail, 5)
+    print(f"      st_xtail (cross-attention + tail): {t_x * 1e3:7.1f} us   attention + st_tail {t_x2 * 1e3:7.1f} us")
+    wq, qcs, qb = L.ln_fold(torch.randn(384, C, generator=g) * C ** -0.5, np.ones(C, np.float32), np.zeros(C, np.float32), None, torch.bfloat16, dev)
+    a1 = att.view(R, 1024, 384)
+    t_b = time_fn(lambda: ops.st_block(a1, wo, b2, x, wq, qcs, qb, ck, cv, wo, b2, w1, aux, w2, b2, wp, b2, r1, out, 1e-5), 5)
+
+    def gemms_xtail():
+      ops.linear(att, wo, h, bias=b2, residual=x)
+      ops.linear(h, wq, qx.view(M, 384), bias=qb, ln_fold=(qcs, 1e-5))
+      ops.st_xtail(qx, ck, cv, wo, b2, h, w1, aux, w2, b2, wp, b2, r1, out, 1e-5)
+
+    t_b2 = time_fn(gemms_xtail, 5)
+    print(f"      st_block (o-projection + q projection + st_xtail): {t_b * 1e3:7.1f} us   2 GEMMs + st_xtail {t_b2 * 1e3:7.1f} us")
