@@ -79,6 +79,7 @@ struct FfnArgs {
 #endif
 
 constexpr uint32_t kOOBf = 0x80000000u;
+constexpr int kNW = 8;
 
 // C: channels (320); KT0: K-tiles of the PRE product (attention width / 64; 0 = no PRE phase);
 // KIND 0: feed-forward only, 1: + proj_out (POST);
@@ -86,11 +87,31 @@ constexpr uint32_t kOOBf = 0x80000000u;
 // against the <= 80 context keys of the panel's sample) runs first, in place in the LDS panel;
 // 4 (FRONT): as 3, but the input rows are the SELF-attention's output: its o-projection + residual and the
 // LayerNorm-folded query projection (unet.py:310-311) run first and leave the queries in the panel
-template <int C, int KT0, int KIND>
-__global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
+template <int N> __device__ __forceinline__ void wait_vm() {      // s_waitcnt vmcnt(N): at most N vector-memory ops in flight
+  static_assert(N >= 0 && N <= 10, "vmcnt");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+}
+
+// NW: waves per workgroup, (NW / 2) x 2 over the 128 x 128 period tile: 8 (wave tile 32 x 64, 2 waves per SIMD) or
+// 4 (wave tile 64 x 64, one wave per SIMD with the whole 512-register file: 1/3 less LDS read traffic per MFMA)
+template <int C, int KT0, int KIND, int NW>
+__global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool PRE = KT0 > 0, POST = KIND != 0, XATT = KIND >= 3, FRONT = KIND == 4;
   constexpr int BM = 128;
+  constexpr int TM = BM / (NW / 2) / 16, RW = 16 * TM;   // 16-row blocks / rows of a wave tile
+  constexpr int NH = 16 / NW;                            // LDS-DMA instructions per staged tile and wave
+  static_assert(NW == 8 || NW == 4, "waves");
   constexpr int KT1 = C / 64;                  // K-tiles of a product over the channels (5)
   constexpr int HID = 4 * C, NCH = HID / 64;   // hidden width, chunks of 64 hidden units (20)
   constexpr int NP2 = (C + 127) / 128;         // 128-column pieces of an N = C product (3)
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows 32 wm .. +31, columns 64 wn .. +63 of a 128 x 128 tile
+  const int wm = wave >> 1, wn = wave & 1;     // wave tile: rows RW wm .., columns 64 wn .. +63 of a 128 x 128 tile
   const int lr = lane & 15, lh = lane >> 4;
   const int m0 = blockIdx.x * BM;
 
@@ -127,38 +148,38 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsWp =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(POST ? p.wp : p.w1), 0, POST ? p.wp_bytes : 0u, 0x00020000);
 
-  // ---- staging geometry: a tile is 16 LDS-DMA instructions of 8 rows; wave w issues instructions w and w + 8.
+  // ---- staging geometry: a tile is 16 LDS-DMA instructions of 8 rows; wave w issues instructions w, w + NW, ...
   // lane l lands at row 8 i + (l >> 3), 16-byte slot l & 7, and fetches chunk (l & 7) ^ ((row >> 1) & 7).
-  int srow[2], sck[2];
+  int srow[NH], sck[NH];
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    srow[h] = (wave + 8 * h) * 8 + (lane >> 3);
+  for (int h = 0; h < NH; ++h) {
+    srow[h] = (wave + NW * h) * 8 + (lane >> 3);
     sck[h] = ((lane & 7) ^ ((srow[h] >> 1) & 7)) * 16;
   }
   // the panel's input rows: KT1 tiles of x, or (PRE) KT0 tiles of the attention output (the last one may lie in
   // the hidden tile's region, which is free until the feed-forward starts)
   constexpr int KTP = PRE ? KT0 : KT1;
   {
-    uint32_t xo[2];
+    uint32_t xo[NH];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       const int m = m0 + srow[h];
       xo[h] = m < p.M ? (uint32_t)((int64_t)m * p.ldx * 2) + sck[h] : kOOBf;
     }
 #pragma unroll
     for (int kt = 0; kt < KTP; ++kt)
 #pragma unroll
-      for (int h = 0; h < 2; ++h)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(smem + kt * TILE + (wave + 8 * h) * 1024), 16,
+      for (int h = 0; h < NH; ++h)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_ptr)(smem + kt * TILE + (wave + NW * h) * 1024), 16,
                                                  xo[h] == kOOBf ? kOOBf : xo[h] + kt * 128, 0, 0, 0);
   }
   // a weight tile whose rows are the output columns 128 pp .. of an N = C product, K bytes kbytes ..
   auto issue_rows = [&](const __amdgpu_buffer_rsrc_t& rs, char* dst, int pp, int kbytes, int row_pitch, int nmax) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < NH; ++h) {
       const int n = 128 * pp + srow[h];
       const uint32_t off = n < nmax ? (uint32_t)(n * row_pitch + kbytes + sck[h]) : kOOBf;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + (wave + 8 * h) * 1024), 16, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr)(dst + (wave + NW * h) * 1024), 16, off, 0, 0, 0);
     }
   };
   // weight tile of step s into ring slot `slot`
@@ -172,9 +193,9 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
       const int c = f / SPC, u = f - c * SPC;
       if (u < KT1) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
           const uint32_t off = (uint32_t)((128 * c + srow[h]) * (C * 2) + u * 128 + sck[h]);
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (lds_ptr)(dst + (wave + 8 * h) * 1024), 16, off, 0, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW1, (lds_ptr)(dst + (wave + NW * h) * 1024), 16, off, 0, 0, 0);
         }
         if (u == KT1 - 1)     // the chunk's (column sums | folded bias): 1 KB, every wave writes the same bytes
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsAux, (lds_ptr)(dst + TILE), 16, (uint32_t)(c * 1024 + lane * 16), 0, 0, 0);
@@ -187,19 +208,19 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
       issue_rows(rsWp, dst, pp, kt * 128, C * 2, C);
     }
   };
-  // DMAs a wave issues for step s (3 where the chunk's aux KB rides along)
+  // DMAs a wave issues for step s (one more where the chunk's aux KB rides along)
   auto n_issued = [&](int s) {
     const int f = s - S0;
-    return (f >= 0 && f < S1 && (f % SPC) == KT1 - 1) ? 3 : 2;
+    return (f >= 0 && f < S1 && (f % SPC) == KT1 - 1) ? NH + 1 : NH;
   };
 
   // ---- fragment addresses ------------------------------------------------------------------------
-  int offA[2][2], offB[2][4];       // [k group][block]: byte offsets inside a 128 x 128-byte tile
+  int offA[2][TM], offB[2][4];       // [k group][block]: byte offsets inside a 128 x 128-byte tile
 #pragma unroll
   for (int kg = 0; kg < 2; ++kg) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = 32 * wm + 16 * i + lr;
+    for (int i = 0; i < TM; ++i) {
+      const int row = RW * wm + 16 * i + lr;
       offA[kg][i] = row * 128 + (((kg * 4 + lh) ^ ((row >> 1) & 7)) << 4);
     }
 #pragma unroll
@@ -209,12 +230,12 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     }
   }
 
-  f32x4 acc1[2][4], acc2[NP2][2][4];
+  f32x4 acc1[TM][4], acc2[NP2][TM][4];
   auto zero_acc2 = [&]() {
 #pragma unroll
     for (int pp = 0; pp < NP2; ++pp)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc2[pp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   };
@@ -222,32 +243,29 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
   // Operands swapped (D = W_frag x A_frag): the lane owns row 16 i + lr and columns 16 j + 4 lh + r.
   // A fragments (resident panel / hidden tile) are read by read_a BEFORE the period's barrier where they do not
   // depend on it; B fragments one k group at a time (6 fragments live: 96 + 32 accumulator registers leave no more).
-  u32x4 fa[2][2];
+  u32x4 fa[2][TM];
   auto read_a = [&](const char* sa) {
 #pragma unroll
     for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[kg][i] = *(const u32x4*)(sa + offA[kg][i]);
+      for (int i = 0; i < TM; ++i) fa[kg][i] = *(const u32x4*)(sa + offA[kg][i]);
   };
-  auto mma_tile = [&](const char* sb, f32x4 (&acc)[2][4]) {
+  auto mma_tile = [&](const char* sb, f32x4 (&acc)[TM][4]) {
     if (LDM_FFN_DBG(p) & 1) return;
+    u32x4 fb[2][4];                 // all 8 B fragments up front: the second k group's reads overlap the first's MFMAs
 #pragma unroll
-    for (int kg = 0; kg < 2; ++kg) {
-      u32x4 fb[4];
-      if (LDM_FFN_DBG(p) & 8) {
+    for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = u32x4{(uint32_t)lane, 1u, 2u, 3u};
-      } else {
+      for (int j = 0; j < 4; ++j)
+        fb[kg][j] = (LDM_FFN_DBG(p) & 8) ? u32x4{(uint32_t)lane, 1u, 2u, 3u} : *(const u32x4*)(sb + offB[kg][j]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[j] = *(const u32x4*)(sb + offB[kg][j]);
-      }
+    for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[j]),
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[kg][j]),
                                                               __builtin_bit_cast(bf16x8, fa[kg][i]), acc[i][j], 0, 0, 0);
-    }
   };
 
   int slot = 0;
@@ -255,10 +273,10 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
   // wave is past its reads of the slot step s + 2 goes into; `drain_lds`: this wave's LDS writes are visible
   auto begin_period = [&](int s, bool drain_lds) {
     if (s + 1 < S) {
-      if (n_issued(s + 1) == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if (n_issued(s + 1) == NH + 1) wait_vm<NH + 1>();
+      else wait_vm<NH>();
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vm<0>();
     }
     if (drain_lds) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -276,37 +294,42 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
   };
 
   // ---- LayerNorm statistics of this wave's 32 rows from the resident panel -------------------------
-  float rs_i[2], nm_i[2];
+  float rs_i[TM], nm_i[TM];
   auto ln_stats = [&]() {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     const bf2 one = __builtin_bit_cast(bf2, 0x3f803f80u);
-    const int row = 32 * wm + (lane & 31), half = lane >> 5;   // lanes l and l + 32 split the row's chunks
-    float s1 = 0.f, s2 = 0.f;
+    const int half = lane >> 5;                                // lanes l and l + 32 split the row's chunks
+    float ln_mu[RW / 32], ln_rs[RW / 32];
 #pragma unroll
-    for (int kt = 0; kt < KT1; ++kt) {
-      const char* base = smem + kt * TILE + row * 128 + half * 64;
+    for (int rg = 0; rg < RW / 32; ++rg) {
+      const int row = RW * wm + 32 * rg + (lane & 31);
+      float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const u32x4 cc = *(const u32x4*)(base + (((j + (row >> 1)) & 3) << 4));
+      for (int kt = 0; kt < KT1; ++kt) {
+        const char* base = smem + kt * TILE + row * 128 + half * 64;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t w = cc[e];
-          const bf2 a = __builtin_bit_cast(bf2, w);
-          s1 = __builtin_amdgcn_fdot2_f32_bf16(a, one, s1, false);
-          s2 = __builtin_amdgcn_fdot2_f32_bf16(a, a, s2, false);
+        for (int j = 0; j < 4; ++j) {
+          const u32x4 cc = *(const u32x4*)(base + (((j + (row >> 1)) & 3) << 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t w = cc[e];
+            const bf2 a = __builtin_bit_cast(bf2, w);
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(a, one, s1, false);
+            s2 = __builtin_amdgcn_fdot2_f32_bf16(a, a, s2, false);
+          }
         }
       }
+      s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 32, 64);
+      const float ik = 1.0f / (float)C;
+      ln_mu[rg] = s1 * ik;
+      ln_rs[rg] = rsqrtf(fmaxf(s2 * ik - ln_mu[rg] * ln_mu[rg], 0.f) + p.eps);
     }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    const float ik = 1.0f / (float)C;
-    const float ln_mu = s1 * ik;
-    const float ln_rs = rsqrtf(fmaxf(s2 * ik - ln_mu * ln_mu, 0.f) + p.eps);
     // statistics of the rows this lane owns in the MFMA layout: row 16 i + lr of the wave tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const float mu = __shfl(ln_mu, 16 * i + lr, 64);
-      rs_i[i] = __shfl(ln_rs, 16 * i + lr, 64);
+    for (int i = 0; i < TM; ++i) {
+      const float mu = __shfl(ln_mu[i >> 1], 16 * (i & 1) + lr, 64);
+      rs_i[i] = __shfl(ln_rs[i >> 1], 16 * (i & 1) + lr, 64);
       nm_i[i] = -rs_i[i] * mu;
     }
   };
@@ -338,8 +361,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     // `landed`: step s's DMAs are known to have landed (steps SA, SA + 1: the h1 epilogue's global loads are
     // younger and have returned; its stores may still be in flight and must not be waited for)
     auto period_f = [&](int s, bool landed) {
-      if (s + 1 >= SF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (!landed) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if (s + 1 >= SF) wait_vm<0>();
+      else if (!landed) wait_vm<NH>();
       __builtin_amdgcn_s_barrier();
     };
     auto ahead_f = [&](int s) {
@@ -349,7 +372,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     issue_f(0, 0);
     issue_f(1, 1);
     zero_acc2();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    wait_vm<2 * NH>();
 #pragma unroll 1
     for (int kt = 0; kt < KT0; ++kt) {
 #pragma unroll
@@ -368,8 +391,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     for (int pp = 0; pp < NP2; ++pp) {
       if (128 * pp + 64 * wn >= C) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = 32 * wm + 16 * i + lr;
+      for (int i = 0; i < TM; ++i) {
+        const int row = RW * wm + 16 * i + lr;
         const int m = min(m0 + row, p.M - 1);
         const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)m * p.ldr0;
 #pragma unroll
@@ -411,8 +434,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
 #pragma unroll
     for (int pp = 0; pp < NP2; ++pp)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = 32 * wm + 16 * i + lr;
+      for (int i = 0; i < TM; ++i) {
+        const int row = RW * wm + 16 * i + lr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
@@ -450,8 +473,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
         const_cast<char*>(p.ctx_vt) + (int64_t)sample * (KT0 * 64) * p.ldv * 2, 0, (uint32_t)(KT0 * 64 * p.ldv * 2), 0x00020000);
     char* img = smem + OFF_R;
 #pragma unroll
-    for (int it = 0; it < XIMG / 1024 / 8 + 1; ++it) {
-      const int n = it * 8 + wave;                    // (wave-uniform)
+    for (int it = 0; it < (XIMG / 1024 + NW - 1) / NW; ++it) {
+      const int n = it * NW + wave;                    // (wave-uniform)
       if (n < XIMG / 1024) {
         const int g = 64 * n + lane, key = g / 48, pos = g - 48 * key;
         const int c = (pos & ~15) | ((pos ^ key) & 15);
@@ -461,7 +484,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    u32x2 pf[4][2][5];
+    u32x2 pf[4][TM][5];
 #pragma unroll
     for (int hh = 0; hh < 4; ++hh) {
       __builtin_amdgcn_sched_barrier(0);              // one head's fragments at a time (registers)
@@ -475,8 +498,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
           kf[jk][kd] = *(const u32x2*)(img + key * (KT0 * 128) + (((c & ~15) | ((c ^ key) & 15)) << 4) + (lh & 1) * 8);
         }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = 32 * wm + 16 * i + lr;
+      for (int i = 0; i < TM; ++i) {
+        const int row = RW * wm + 16 * i + lr;
         u32x2 qf[3];
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd) {
@@ -512,8 +535,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     }
     __builtin_amdgcn_s_barrier();                     // every wave is done with the keys
 #pragma unroll
-    for (int it = 0; it < XIMG / 1024 / 8 + 1; ++it) {
-      const int n = it * 8 + wave;
+    for (int it = 0; it < (XIMG / 1024 + NW - 1) / NW; ++it) {
+      const int n = it * NW + wave;
       if (n < XIMG / 1024) {
         const int g = 64 * n + lane, dim = g / 10, pos = g - 10 * dim;
         const int c = pos ^ ((dim >> 3) & 1);
@@ -540,8 +563,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
           vf[jd][jk] = v;
         }
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = 32 * wm + 16 * i + lr;
+      for (int i = 0; i < TM; ++i) {
+        const int row = RW * wm + 16 * i + lr;
         f32x4 o[3];
 #pragma unroll
         for (int jd = 0; jd < 3; ++jd) {
@@ -574,7 +597,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
 
   // ---- PRE: h = r0 + bo + Wo . att ------------------------------------------------------------------
   if constexpr (PRE) {
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // the panel's DMAs are older than the two weight tiles
+    wait_vm<2 * NH>();                                   // the panel's DMAs are older than the two weight tiles
 #pragma unroll 1
     for (int kt = 0; kt < KT0; ++kt) {
 #pragma unroll
@@ -593,8 +616,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     for (int pp = 0; pp < NP2; ++pp) {
       if (128 * pp + 64 * wn >= C) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = 32 * wm + 16 * i + lr;
+      for (int i = 0; i < TM; ++i) {
+        const int row = RW * wm + 16 * i + lr;
         const int m = min(m0 + row, p.M - 1);
         const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)m * p.ldr0;
 #pragma unroll
@@ -621,8 +644,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   } else {
-    if (n_issued(0) + n_issued(1) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    if (n_issued(0) + n_issued(1) == 2 * NH) wait_vm<2 * NH>();
+    else wait_vm<2 * NH + 1>();
     __builtin_amdgcn_s_barrier();
   }
 
@@ -643,7 +666,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
       if (u < KT1) {
         if (u == 0) {
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
@@ -659,7 +682,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
             const f32x4 bv = *(const f32x4*)(aux + 128 + 64 * wn + 16 * jp + 4 * lh);
             const f32x4 bg = *(const f32x4*)(aux + 128 + 64 * wn + 16 * (jp + 2) + 4 * lh);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < TM; ++i) {
               float hv[4];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -671,7 +694,7 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
               pk[0] = pack_bf2(hv[0], hv[1]);
               pk[1] = pack_bf2(hv[2], hv[3]);
               // hidden column (inside the chunk) 32 wn + 16 jp + 4 lh + r -> 16-byte chunk 4 wn + 2 jp + (lh >> 1)
-              const int row = 32 * wm + 16 * i + lr;
+              const int row = RW * wm + 16 * i + lr;
               const int ck = (4 * wn + 2 * jp + (lh >> 1)) ^ ((row >> 1) & 7);
               *(u32x2*)(smem + OFF_H + row * 128 + ck * 16 + (lh & 1) * 8) = pk;
             }
@@ -693,8 +716,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
     for (int pp = 0; pp < NP2; ++pp) {
       if (128 * pp + 64 * wn >= C) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = 32 * wm + 16 * i + lr;
+      for (int i = 0; i < TM; ++i) {
+        const int row = RW * wm + 16 * i + lr;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
@@ -736,8 +759,8 @@ __global__ __launch_bounds__(512) void st_tail_kernel(FfnArgs p) {
   for (int pp = 0; pp < NP2; ++pp) {
     if (128 * pp + 64 * wn >= C) continue;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = 32 * wm + 16 * i + lr;
+    for (int i = 0; i < TM; ++i) {
+      const int row = RW * wm + 16 * i + lr;
       const int m = m0 + row;
       if (m >= p.M) continue;
       bf16_t* orow = (bf16_t*)p.out + (int64_t)m * p.ldo;
@@ -803,7 +826,7 @@ extern "C" int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const f
   FfnArgs a;
   fill_common(&a, x, ldx, w1, aux, w2, b2, out, ldo, M, C, C, eps);
   dim3 grid((M + 127) / 128);
-  hipLaunchKernelGGL((st_tail_kernel<320, 0, 0>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((st_tail_kernel<320, 0, 0, kNW>), grid, dim3(64 * kNW), 0, (hipStream_t)stream, a);
   return ldm_launch_status("ldm_ffn_geglu");
 }
 
@@ -823,7 +846,7 @@ extern "C" int ldm_st_tail(const void* att, int64_t lda, int K0, const void* wo,
   a.wo = (const char*)wo; a.bo = bo; a.r0 = (const char*)r0; a.ldr0 = ldr0; a.wo_bytes = (uint32_t)(C * K0 * 2);
   a.wp = (const char*)wp; a.bp = bp; a.r1 = (const char*)r1; a.ldr1 = ldr1; a.wp_bytes = (uint32_t)(C * C * 2);
   dim3 grid((M + 127) / 128);
-  hipLaunchKernelGGL((st_tail_kernel<320, 6, 1>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((st_tail_kernel<320, 6, 1, kNW>), grid, dim3(64 * kNW), 0, (hipStream_t)stream, a);
   return ldm_launch_status("ldm_st_tail");
 }
 
@@ -849,7 +872,7 @@ extern "C" int ldm_st_xtail(const void* q, int64_t ldq, int K0, const void* ctx_
   a.wp = (const char*)wp; a.bp = bp; a.r1 = (const char*)r1; a.ldr1 = ldr1; a.wp_bytes = (uint32_t)(C * C * 2);
   a.ctx_k = (const char*)ctx_k; a.ctx_vt = (const char*)ctx_vt; a.Tk = Tk; a.ldv = ldv; a.T = T;
   dim3 grid((M + 127) / 128);
-  hipLaunchKernelGGL((st_tail_kernel<320, 6, 3>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((st_tail_kernel<320, 6, 3, kNW>), grid, dim3(64 * kNW), 0, (hipStream_t)stream, a);
   return ldm_launch_status("ldm_st_xtail");
 }
 
@@ -881,6 +904,6 @@ extern "C" int ldm_st_block(const void* att, int64_t lda, int K0, const void* wo
   a.wp = (const char*)wp; a.bp = bp; a.r1 = (const char*)r1; a.ldr1 = ldr1; a.wp_bytes = (uint32_t)(C * C * 2);
   a.ctx_k = (const char*)ctx_k; a.ctx_vt = (const char*)ctx_vt; a.Tk = Tk; a.ldv = ldv; a.T = T;
   dim3 grid((M + 127) / 128);
-  hipLaunchKernelGGL((st_tail_kernel<320, 6, 4>), grid, dim3(512), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((st_tail_kernel<320, 6, 4, kNW>), grid, dim3(64 * kNW), 0, (hipStream_t)stream, a);
   return ldm_launch_status("ldm_st_block");
 }
