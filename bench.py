@@ -377,7 +377,9 @@ def main():
                                  f"workload (profiles/{os.path.basename(tj) if tj else '-'}; tools/profile_round.sh reproduces them)"),
                 "kernel": ("every launch of ldm_gemm: gemm_kernel<T,BM,BN,WM,WN,MODE,MF,ST,NS> + gemm3_kernel<TN,MODE,EPI> (Dense/1x1/"
                            "projection GEMMs incl. the LayerNorm-folded ones + implicit-GEMM 3x3 convs) + their split-K reduces (plain "
-                           "launches, and the extra time of the GroupNorm launches that complete a deferred reduce)"),
+                           "launches, and the extra time of the GroupNorm launches that complete a deferred reduce) + the row-panel "
+                           "launches that chain the transformer block's products (st_tail_kernel: ldm_st_block / ldm_ffn_geglu; the "
+                           "cross-attention inside ldm_st_block is timed with it, its FLOPs are not counted)"),
                 "launches_per_unet_step": n_launches, "ms_per_unet_step_in_kernel": gemm_ms,
                 "avg_launch_us": gemm_ms * 1e3 / max(n_launches, 1),
                 "ms_unet_step_graph_full": t_full, "ms_unet_step_graph_without_family": t_rest,

@@ -25,6 +25,15 @@
 // skeleton (160 barriers, waits, A reads), 52 the MFMAs, 22 the GEGLU epilogue, 17 the B fragment reads, 7 the
 // staging -- they add up: the two waves of a SIMD run in lockstep and nothing overlaps.  The per-layer launches
 // this replaces cost more because each pays its own fill, drain and HBM round trip.
+// Schedules measured against this one (same probe, feed-forward alone, 108 us):
+//   * two wave groups half a period apart (load phase / matrix phase, two barriers per period, s_setprio): 119.7 us
+//     -- a workgroup barrier costs ~0.075 us here, as much as the overlap buys;
+//   * 4 waves with wave tiles 64 x 64 and the whole 512-register file (1/3 less LDS read traffic): 119.7 us -- one
+//     wave per SIMD has nobody to hide its LDS latency behind;
+//   * all 8 B fragments read before the first MFMA: no change (109 us);
+//   * fully unrolled phase loops (the compiler's choice without `#pragma unroll 1`): the same in a hot loop, but
+//     in situ, where every launch starts with a cold instruction cache, straight-line code is fetched at ~1 us
+//     per period: the 33 extra periods of ldm_st_block cost 37 us unrolled, 17 us as loops.
 #include "common.h"
 #include <stdlib.h>
 
@@ -111,7 +120,7 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
   constexpr int BM = 128;
   constexpr int TM = BM / (NW / 2) / 16, RW = 16 * TM;   // 16-row blocks / rows of a wave tile
   constexpr int NH = 16 / NW;                            // LDS-DMA instructions per staged tile and wave
-  static_assert(NW == 8 || NW == 4, "waves");
+  static_assert(NW == 8 || NW == 4, "waves");          // (NW = 4 is not instantiated: see the file comment)
   constexpr int KT1 = C / 64;                  // K-tiles of a product over the channels (5)
   constexpr int HID = 4 * C, NCH = HID / 64;   // hidden width, chunks of 64 hidden units (20)
   constexpr int NP2 = (C + 127) / 128;         // 128-column pieces of an N = C product (3)

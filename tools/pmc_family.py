@@ -42,7 +42,7 @@ for path in args:
       continue
     # gn_fused_kernel<..., true> = ldm_groupnorm_splitk: the split-K reduce of a conv fused into the
     # GroupNorm that consumes it -- counted with the GEMM family (it reads that family's f32 slabs)
-    f = ("gemm_kernel" if ("gemm_kernel<" in n or "gemm3_kernel<" in n) else "attn_kernel" if "attn_kernel" in n else
+    f = ("gemm_kernel" if ("gemm_kernel<" in n or "gemm3_kernel<" in n or "st_tail_kernel<" in n) else "attn_kernel" if "attn_kernel" in n else
          "groupnorm_splitk" if ("gn_fused_kernel<" in n and ", true>" in n) else
          "groupnorm" if "gn_" in n else "layernorm" if "layernorm" in n else
          "splitk_reduce" if "splitk" in n else "other")
@@ -78,7 +78,7 @@ if out_json:
     for c, v in totals.get(extra, {}).items():
       g[c] = g.get(c, 0.0) + v
   res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py; "
-                   "family = gemm_kernel<...> + gemm3_kernel<...> + splitk_epilogue* + the GroupNorm launches that complete a deferred split-K product (gn_fused_kernel<..., true>: their own GroupNorm read/write is included, an over-count); per U-Net evaluation (dispatches between time_embedding_kernel and cfg_ddim_kernel only)",
+                   "family = gemm_kernel<...> + gemm3_kernel<...> + st_tail_kernel<...> (row-panel chains) + splitk_epilogue* + the GroupNorm launches that complete a deferred split-K product (gn_fused_kernel<..., true>: their own GroupNorm read/write is included, an over-count); per U-Net evaluation (dispatches between time_embedding_kernel and cfg_ddim_kernel only)",
          "fetch_kb_raw_per_eval": g.get("FETCH_SIZE"), "write_kb_raw_per_eval": g.get("WRITE_SIZE"),
          "launches_per_eval": (totals.get("_launches_per_eval", {}).get("gemm_kernel", 0) +
                                totals.get("_launches_per_eval", {}).get("splitk_reduce", 0) +

@@ -27,7 +27,7 @@ def main():
   rows = list(csv.DictReader(open(args.stats_csv)))
   tot = sum(float(r["TotalDurationNs"]) for r in rows)
   evals = sum(int(r["Calls"]) for r in rows if "time_embedding_kernel" in r["Name"])
-  gemm = [r for r in rows if "gemm_kernel<" in r["Name"] or "gemm3_kernel<" in r["Name"]]
+  gemm = [r for r in rows if "gemm_kernel<" in r["Name"] or "gemm3_kernel<" in r["Name"] or "st_tail_kernel<" in r["Name"]]
   # split-K reduces: the plain reduce launches and the GroupNorm launches that complete a deferred product
   red = [r for r in rows if "splitk_epilogue" in r["Name"] or ("gn_fused_kernel<" in r["Name"] and ", true>" in r["Name"])]
   red_ns = sum(float(r["TotalDurationNs"]) for r in red)
@@ -37,12 +37,12 @@ def main():
   print(f"* total kernel time: {tot / 1e6:.1f} ms over {sum(int(r['Calls']) for r in rows)} dispatches")
   print(f"* U-Net evaluations in the run (time_embedding_kernel dispatches): {evals}")
   if evals:
-    print(f"* MFMA GEMM/conv family (`gemm_kernel<...>`, all tile shapes): {gemm_ns / 1e6:.1f} ms, "
+    print(f"* MFMA GEMM/conv family (`gemm_kernel<...>` / `gemm3_kernel<...>` / `st_tail_kernel<...>`, all tile shapes): {gemm_ns / 1e6:.1f} ms, "
           f"{gemm_calls} launches = **{gemm_ns / 1e6 / evals:.3f} ms per U-Net evaluation** "
           f"(incl. the text encoder's and decoder's launches, which add a few %), "
           f"average launch {gemm_ns / 1e3 / max(gemm_calls, 1):.1f} us")
-    print(f"* the family as bench.py's `roofline` defines it (every launch made by `ldm_gemm`: `gemm_kernel<...>` "
-          f"+ its split-K reduce `splitk_epilogue*` / `gn_fused_kernel<..., true>` = reduce fused with the next GroupNorm): **{(gemm_ns + red_ns) / 1e6 / evals:.3f} ms per U-Net evaluation**, "
+    print(f"* the family as bench.py's `roofline` defines it (every launch made by `ldm_gemm`: `gemm_kernel<...>` / `gemm3_kernel<...>`, the row-panel chains `st_tail_kernel<...>` "
+          f"+ the split-K reduces `splitk_epilogue*` / `gn_fused_kernel<..., true>` = reduce fused with the next GroupNorm): **{(gemm_ns + red_ns) / 1e6 / evals:.3f} ms per U-Net evaluation**, "
           f"{(gemm_calls + sum(int(r['Calls']) for r in red)) / evals:.0f} kernel launches per evaluation")
     print(f"* all kernels: {tot / 1e6 / evals:.3f} ms per U-Net evaluation (upper bound: includes text encoder + decoder)")
   if args.bench_json:
