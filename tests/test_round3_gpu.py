@@ -460,6 +460,31 @@ def test_st_block_from_self_attention_output_to_block_output(dev, R, T, Tk):
   assert r < 6e-3 and r <= r2 * 1.2 + 1e-4 and d < 3e-3
 
 
+def test_row_panel_launches_reject_what_they_cannot_do(dev):
+  """Loud errors, nothing launched: other widths, f32, query rows per sample not a multiple of 128, too many keys, an
+  output that aliases an input of ldm_st_block (out is its scratch)."""
+  from ldm_tf2_amd._lib import LdmHipError
+  o = ops()
+  C, K0 = 320, 384
+  z = lambda *sh, dt=BF: torch.zeros(*sh, dtype=dt, device=dev)
+  w1, aux, w2, b = z(8 * C, C), z(8 * C * 2, dt=torch.float32), z(C, 4 * C), z(C, dt=torch.float32)
+  wo, wp, wq, qv = z(C, K0), z(C, C), z(K0, C), z(K0, dt=torch.float32)
+  x = z(256, C)
+  with pytest.raises(LdmHipError):                                   # f32 rows
+    o.ffn_geglu(z(256, C, dt=torch.float32), w1, aux, w2, b, z(256, C, dt=torch.float32), 1e-5)
+  assert not o.ffn_geglu_supported(z(256, 640))                      # other widths: the per-layer launches
+  q, ck, cv = z(2, 128, K0), z(2, 77, K0), z(2, K0, 80)
+  out = z(256, C)
+  o.st_xtail(q, ck, cv, wo, b, x, w1, aux, w2, b, wp, b, x, out, 1e-5)           # the accepted form
+  with pytest.raises(LdmHipError):                                   # 96 query rows per sample
+    o.st_xtail(z(2, 96, K0), ck, cv, wo, b, z(192, C), w1, aux, w2, b, wp, b, z(192, C), z(192, C), 1e-5)
+  with pytest.raises(LdmHipError):                                   # 96 keys: more than one key tile
+    o.st_xtail(q, z(2, 96, K0), z(2, K0, 96), wo, b, x, w1, aux, w2, b, wp, b, x, out, 1e-5)
+  with pytest.raises(LdmHipError):                                   # out aliases the residual
+    o.st_block(q, wo, b, x, wq, qv, qv, ck, cv, wo, b, w1, aux, w2, b, wp, b, x, x, 1e-5)
+  torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("fused,tail,block", [(True, True, True), (True, True, False), (True, False, False), (False, False, False)])
 def test_unet_fused_ffn_matches_the_unfused_unet(dev, fused, tail, block):
   """A C = 320 U-Net level through ldm_st_block / ldm_st_xtail / ldm_ffn_geglu (ffn_min_rows=1) against the oracle
