@@ -460,6 +460,51 @@ def test_st_block_from_self_attention_output_to_block_output(dev, R, T, Tk):
   assert r < 6e-3 and r <= r2 * 1.2 + 1e-4 and d < 3e-3
 
 
+def test_st_block_at_the_benchmark_size_equals_the_per_layer_launches(dev):
+  """BASELINE configs[2]'s 32x32 level (R = 32 rows of T = 1024 tokens): ldm_st_block against the eight per-layer
+  launches it replaces (ldm_gemm x 7 with the LayerNorm folds, ldm_attention_ms) on the same operands; every
+  sample / panel is covered, rows differ only by bf16 rounding of the intermediates."""
+  o = ops()
+  C, H, S, sp, R, T, Tk = 320, 8, 40, 48, 32, 1024, 77
+  K0, M = H * sp, R * T
+  g = torch.Generator().manual_seed(150)
+  rn = lambda *sh, sc=1.0: (torch.randn(*sh, generator=g) * sc)
+  att1 = rn(R, T, K0).to(BF).to(dev)
+  r0, r1 = rn(M, C).to(BF).to(dev), rn(M, C).to(BF).to(dev)
+  wo1, wo2 = (rn(C, K0, sc=K0 ** -0.5).to(BF).to(dev) for _ in range(2))
+  wp = rn(C, C, sc=C ** -0.5).to(BF).to(dev)
+  bo1, bo2, b2, bp = (rn(C).to(dev) for _ in range(4))
+  gam, bet = (1.0 + 0.3 * rn(C)).numpy(), (0.2 * rn(C)).numpy()
+  wq_nk = torch.zeros(H, sp, C); wq_nk[:, :S] = rn(H, S, C, sc=C ** -0.5) * (S ** -0.5 * L.MS_LOG2E)
+  wq, qcs, qb = L.ln_fold(wq_nk.reshape(K0, C), gam, bet, None, BF, dev)
+  k1, b1 = rn(C, 8 * C, sc=C ** -0.5).numpy(), rn(8 * C).numpy()
+  gw, gb = L.geglu_kernel(k1, b1, torch.float32, "cpu")
+  w1, cs, bb = L.ln_fold(gw, gam, bet, gb.numpy(), BF, dev)
+  aux = L.ffn_aux(cs, bb)
+  w2 = rn(C, 4 * C, sc=(4 * C) ** -0.5).to(BF).to(dev)
+  kd = torch.zeros(R, Tk, H, sp); kd[..., :S] = rn(R, Tk, H, S); kd[..., L.MS_DIM] = 1.0
+  vv = torch.zeros(R, Tk, H, sp); vv[..., :S] = rn(R, Tk, H, S); vv[..., L.MS_DIM] = 1.0
+  vt = torch.zeros(R, K0, 80); vt[:, :, :Tk] = vv.reshape(R, Tk, K0).permute(0, 2, 1)
+  kd, vt = kd.reshape(R, Tk, K0).to(BF).to(dev), vt.to(BF).to(dev)
+  out = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+  o.st_block(att1, wo1, bo1, r0, wq, qcs, qb, kd, vt, wo2, bo2, w1, aux, w2, b2, wp, bp, r1, out, 1e-5)
+  h1, h2, y, ref = (torch.empty(M, C, dtype=BF, device=dev) for _ in range(4))
+  q, a2 = torch.empty(R, T, K0, dtype=BF, device=dev), torch.empty(R, T, K0, dtype=BF, device=dev)
+  ff = torch.empty(M, 4 * C, dtype=BF, device=dev)
+  o.linear(att1.view(M, K0), wo1, h1, bias=bo1, residual=r0)
+  o.linear(h1, wq, q.view(M, K0), bias=qb, ln_fold=(qcs, 1e-5))
+  o.attention(q, kd, vt, a2, H, sp, S ** -0.5, matrix_softmax=True)
+  o.linear(a2.view(M, K0), wo2, h2, bias=bo2, residual=h1)
+  o.linear(h2, w1, ff, bias=bb, act=o.ACT_GEGLU, ln_fold=(cs, 1e-5))
+  o.linear(ff, w2, y, bias=b2, residual=h2)
+  o.linear(y, wp, ref, bias=bp, residual=r1)
+  assert torch.isfinite(out.float()).all()
+  d = (out.float() - ref.float()).view(R, T, C)
+  per_sample = (d.norm(dim=(1, 2)) / ref.float().view(R, T, C).norm(dim=(1, 2))).cpu()
+  print(f"st_block at M = {M}: rel per sample max {per_sample.max():.3e}, min {per_sample.min():.3e}")
+  assert float(per_sample.max()) < 6e-3
+
+
 def test_row_panel_launches_reject_what_they_cannot_do(dev):
   """Loud errors, nothing launched: other widths, f32, query rows per sample not a multiple of 128, too many keys, an
   output that aliases an input of ldm_st_block (out is its scratch)."""
