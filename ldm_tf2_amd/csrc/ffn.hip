@@ -1,11 +1,18 @@
-// Row-panel kernel for the tail of the BasicTransformerBlock / SpatialTransformer at the 320-channel level
-// (unet.py:311-313, :323-325, :335-338, :357-365), bf16:
+// Row-panel kernel for the BasicTransformerBlock / SpatialTransformer at the 320-channel level, from the
+// self-attention's output to the block's output (unet.py:310-313, :323-325, :335-338, :357-365), bf16:
 //
-//   [PRE ]  h  = r0 + bo + Wo . att                       cross-attention output projection + residual (:312)
+//   [FRONT] h1 = r0 + bo1 + Wo1 . att1                    self-attention output projection + residual (:310)
+//           q  = Wq' . LayerNorm(h1)                      cross-attention query projection (:311, :262)
+//   [XATT ] att = softmax(q K^T) V                        cross-attention against the <= 80 context keys (:273-291)
+//   [PRE ]  h  = h1 + bo + Wo . att                       cross-attention output projection + residual (:312)
 //           y  = h + b2 + W2 . ( a * gelu(g) ),  (a | g) = W1 . LayerNorm(h) + b1       feed-forward (:313)
 //   [POST]  out = r1 + bp + Wp . y                        proj_out of the SpatialTransformer + its residual (:363-365)
 //
-// as ONE launch per 128-row panel of the residual stream instead of up to four GEMM launches + a LayerNorm.
+// Entry points by how much of the chain they take: ldm_ffn_geglu (the feed-forward), ldm_st_tail (PRE .. POST),
+// ldm_st_xtail (XATT .. POST), ldm_st_block (all of it: one launch instead of seven GEMM launches and an attention
+// launch).
+//
+// ONE launch per 128-row panel of the residual stream.
 // The design is a row-panel kernel, not a per-layer GEMM:
 //   * the panel (128 rows x 320 channels, 80 KB, the GEMM kernels' swizzled K-tile image) stays RESIDENT in
 //     LDS and is rewritten in place from phase to phase: att rows -> h -> y.  It is the A operand of every
