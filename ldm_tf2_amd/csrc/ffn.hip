@@ -38,6 +38,9 @@
 //   * 4 waves with wave tiles 64 x 64 and the whole 512-register file (1/3 less LDS read traffic): 119.7 us -- one
 //     wave per SIMD has nobody to hide its LDS latency behind;
 //   * all 8 B fragments read before the first MFMA: no change (109 us);
+//   * B fragments read one step ahead (second register set; the reads of step s + 1 issued between the barrier and
+//     the MFMAs of step s; request distance 3): parity green, 110.2 us (ldm_st_block 165.5 vs 158 us; 60 - 148 B of
+//     scratch): the LDS reads are not what the period waits for;
 //   * fully unrolled phase loops (the compiler's choice without `#pragma unroll 1`): the same in a hot loop, but
 //     in situ, where every launch starts with a cold instruction cache, straight-line code is fetched at ~1 us
 //     per period: the 33 extra periods of ldm_st_block cost 37 us unrolled, 17 us as loops.
