@@ -6,7 +6,8 @@ so only same-process numbers rank two launch forms.
 
     python tools/ab_step.py --batch 16 [--latent 32] [--rounds 6] name=kw:val,kw:val ...
 e.g. python tools/ab_step.py base=fold_layernorm:0,defer_reduce:0 fold=defer_reduce:0 both=
-(values: ints; a variant's kwargs go to the UNet constructor)
+(values: ints; a variant's kwargs go to the UNet constructor; `plans:<file>` captures the variant with that launch-plan
+table instead of the packaged ones)
 """
 import argparse
 import os
@@ -17,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench as BN  # noqa: E402
-from ldm_tf2_amd import weights as Wt  # noqa: E402
+from ldm_tf2_amd import ops, weights as Wt  # noqa: E402
 from ldm_tf2_amd.unet import UNet  # noqa: E402
 
 
@@ -41,9 +42,18 @@ def main():
   for spec in args.variants:
     name, _, kws = spec.partition("=")
     kw = {}
+    plans = None
     for item in filter(None, kws.split(",")):
       k, _, v = item.partition(":")
-      kw[k] = int(v)
+      if k == "plans":              # this variant's launch-plan table (a tuner output) instead of the packaged ones
+        plans = v
+      else:
+        kw[k] = int(v)
+    ops.clear_plans()               # (a captured graph keeps the plans it was captured with)
+    if plans:
+      ops.load_plans(plans)
+    else:
+      ops._load_default_plans()
     unet = UNet(**cfg, weights=w, dtype=torch.bfloat16, device=dev, **kw)
     unet.set_context(ctx)
     out = torch.empty(R, args.latent, args.latent, 4, device=dev)
