@@ -33,8 +33,12 @@
 // staging -- they add up: the two waves of a SIMD run in lockstep and nothing overlaps.  The per-layer launches
 // this replaces cost more because each pays its own fill, drain and HBM round trip.
 // Schedules measured against this one (same probe, feed-forward alone, 108 us):
-//   * two wave groups half a period apart (load phase / matrix phase, two barriers per period, s_setprio): 119.7 us
-//     -- a workgroup barrier costs ~0.075 us here, as much as the overlap buys;
+//   * two wave groups half a period apart (load phase / matrix phase, two barriers per period, s_setprio): 119.7 us;
+//   * the same rotation with ONE barrier per period (both groups run the same stream L(s) M(s) L(s+1) ..., group 0
+//     synchronises in front of L(s), group 1 between L(s) and M(s), so that between two barriers one executes
+//     L(s) M(s) and the other M(s-1) L(s); same waits, requests and registers as in lockstep): parity green, 118.9 us
+//     (ldm_st_block 176.5 vs 158) -- one wave's MFMAs beside the other's LDS reads on a SIMD is not faster than both
+//     reading, then both multiplying; what the period waits for is neither of the two;
 //   * 4 waves with wave tiles 64 x 64 and the whole 512-register file (1/3 less LDS read traffic): 119.7 us -- one
 //     wave per SIMD has nobody to hide its LDS latency behind;
 //   * all 8 B fragments read before the first MFMA: no change (109 us);
