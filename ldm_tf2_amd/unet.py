@@ -123,7 +123,7 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True):
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -156,6 +156,17 @@ class UNet:
     self._ffn_min_rows = int(ffn_min_rows)        # ... from 192 panels of 128 rows on (3/4 of the CUs busy)
     self._gn_single = bool(gn_single_launch)      # False: partial-sums + apply launches everywhere (A/B)
     self._defer_reduce = bool(defer_reduce)   # split-K reduces fused into the consuming GroupNorm (A/B: False)
+    # lanes: the rows of one evaluation walked as `lanes` coarse, independent branches (no op of the U-Net
+    # crosses rows, unet.py:118-138): branch i takes rows [i R / lanes, (i+1) R / lanes) on its own stream with
+    # its own scratch and split-K workspace -- ONE fork after the timestep MLP, ONE join before the caller's
+    # next launch -- so one branch's latency-bound launches run beside the other's convolutions.  Each
+    # branch runs the launch plans of ITS row count.
+    self._lanes = max(1, int(lanes))
+    # lane_levels = L: only the levels from L down (the downsample conv into level L .. the upsample conv out of it)
+    # are branched, the full-resolution levels run unbranched on all rows; None: the whole evaluation
+    self._lane_levels = None if lane_levels is None else int(lane_levels)
+    self._lane_state = {}
+    self._rows = None                     # a lane's slice of the rows (context K / V^T); None = all rows
     self._pend = None
     self._fuse_cache = {}
     self._model_channels = model_channels
@@ -389,11 +400,12 @@ class UNet:
     hb = B_.get("st_b", (R, T, c), dt)
     q = B_.get("st_q", (R, T, hs), dt)
     panel = (fold is not None and st.ffn_aux is not None and self._fused_ffn and R * T >= self._ffn_min_rows)
+    ctx_k, ctx_vt = (st.ctx_k, st.ctx_vt) if self._rows is None else (st.ctx_k[self._rows], st.ctx_vt[self._rows])
     xtail = (panel and self._fused_tail and self._fused_xattn and ms and hs == 384 and T % 128 == 0
-             and st.ctx_k.shape[1] <= 80 and st.ctx_vt.shape[2] >= 80)
+             and ctx_k.shape[1] <= 80 and ctx_vt.shape[2] >= 80)
     if xtail and self._fused_block:
       # everything from the self-attention's output to the block's output: ONE row-panel launch (ldm_st_block)
-      ops.st_block(att, st.o1[0], st.o1[1], ha, fold["q2"][0], fold["q2"][1], fold["q2"][2], st.ctx_k, st.ctx_vt,
+      ops.st_block(att, st.o1[0], st.o1[1], ha, fold["q2"][0], fold["q2"][1], fold["q2"][2], ctx_k, ctx_vt,
                    st.o2[0], st.o2[1], fold["geglu"][0], st.ffn_aux, st.ff_out[0], st.ff_out[1], st.proj_out[0],
                    st.proj_out[1], x, out, LN_EPS)
       return out
@@ -407,10 +419,10 @@ class UNet:
       ops.linear(ln, st.q2, q)
     if xtail:
       # ... with the cross-attention itself in front of it, in place in the LDS panel
-      ops.st_xtail(q, st.ctx_k, st.ctx_vt, st.o2[0], st.o2[1], hb, fold["geglu"][0], st.ffn_aux, st.ff_out[0],
+      ops.st_xtail(q, ctx_k, ctx_vt, st.o2[0], st.o2[1], hb, fold["geglu"][0], st.ffn_aux, st.ff_out[0],
                    st.ff_out[1], st.proj_out[0], st.proj_out[1], x, out, LN_EPS)
       return out
-    ops.attention(q, st.ctx_k, st.ctx_vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
+    ops.attention(q, ctx_k, ctx_vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
     if panel and self._fused_tail and hs == 384:
       # o-projection + residual, LayerNorm -> GEGLU -> FF-out + residual, proj_out + residual: ONE row-panel
       # launch; the two intermediate residual-stream tensors live only in LDS (unet.py:312-313, :363-365)
@@ -442,24 +454,87 @@ class UNet:
     """x f32 [R,h,w,4].  Timestep either per row (`t_rows` int32 [R]) or, for the
     graph-replayed DDIM loop, `steps[*index]` for every row.  `shared_t=True` with
     t_rows declares that all rows carry t_rows[0]."""
-    # launch plans measured for this step configuration (ops.plan_scope), none otherwise
-    with ops.plan_scope(x.shape[0], x.shape[1], self.dtype), ops.workspace_scope(self._ws):
-      self._pend = None
-      try:
-        return self._forward(x, t_rows, steps, index, out, shared_t)
-      finally:
-        self._flush()
-
-  def _forward(self, x, t_rows, steps, index, out, shared_t):
     assert x.dtype == torch.float32 and x.is_contiguous()
     R, h, w, _ = x.shape
     nlev = max(self.skip_lvl)
     assert h % (1 << nlev) == 0 and w % (1 << nlev) == 0, "latent size must divide by 2**levels"
     assert self.sts[0].ctx_k is not None and self._ctx_rows == R, "call set_context(context) first"
-    B_, dt, mc = self.buf, self.dtype, self._model_channels
+    if out is None:
+      out = torch.empty(R, h, w, self._out_channels, dtype=torch.float32, device=self.device)
+    tall = self._temb(R, t_rows, steps, index, shared_t)
+    env = self._env(x, tall, out)
+    prog = env["prog"]
+    n = self._lanes if (self._lanes > 1 and R % self._lanes == 0) else 1
+    if n == 1:
+      self._segment(env, 0, len(prog), None)
+      return out
+    # coarse row branches over the step range [a, b): lane 0 on the caller's stream, the others on side streams of
+    # their own (ONE fork, ONE join); under graph capture the side streams join the capture through the event
+    # waits.  Steps outside the range run unbranched on all rows.
+    a, b = self._lane_range(env)
+    Rl = R // n
+    cur = torch.cuda.current_stream(self.device)
+    lanes = self._lane_views(n)
+    if a > 0:
+      self._segment(env, 0, a, None)
+    for i in range(1, n):
+      ln, side = lanes[i]
+      side.wait_stream(cur)
+      with torch.cuda.stream(side):
+        ln._segment(env, a, b, slice(i * Rl, (i + 1) * Rl))
+    lanes[0][0]._segment(env, a, b, slice(0, Rl))
+    for i in range(1, n):
+      cur.wait_stream(lanes[i][1])
+    if b < len(prog):
+      self._segment(env, b, len(prog), None)
+    return out
+
+  def _lane_range(self, env):
+    """Step range the row branches cover: the whole evaluation (`lane_levels` None) or the levels from
+    `lane_levels` down -- first step = the downsample conv into that level, last = the upsample conv out of it."""
+    prog = env["prog"]
+    if self._lane_levels is None:
+      return 0, len(prog)
+    lv = [st[-1] for st in prog]
+    inside = [i for i, l in enumerate(lv) if l >= self._lane_levels]
+    return (inside[0], inside[-1] + 1) if inside else (0, 0)
+
+  def _lane_views(self, n):
+    """Shallow views of this model, one per branch: the weights are shared, scratch buffers, split-K workspace and
+    the deferred-product slot are the view's own (built once per lane count, before any capture needs them)."""
+    views = self._lane_state.get(n)
+    if views is None:
+      import copy
+      views = []
+      for i in range(n):
+        v = copy.copy(self)
+        v.buf = L.Buffers(self.device)
+        v._ws = ops.new_workspace(self.device)
+        v._pend = None
+        v._lanes, v._lane_state = 1, {}
+        views.append((v, torch.cuda.Stream(self.device) if i else None))
+      self._lane_state[n] = views
+    return views
+
+  def _segment(self, env, a, b, rows):
+    """Steps [a, b) of the evaluation on the rows `rows` (None = all), with this view's scratch and workspace and
+    the launch plans measured for this row count (ops.plan_scope)."""
+    x = env["x"]
+    nr = x.shape[0] if rows is None else rows.stop - rows.start
+    self._rows = rows
+    with ops.plan_scope(nr, x.shape[1], self.dtype), ops.workspace_scope(self._ws):
+      self._pend = None
+      self._gnp = self.buf.get("gn_partial", (nr * 128 * 32 * 2,), torch.float32)
+      try:
+        for st in env["prog"][a:b]:
+          self._exec(env, st, rows)
+      finally:
+        self._flush()
+
+  def _temb(self, R, t_rows, steps, index, shared_t):
+    """timestep embedding + MLP + all temb projections (unet.py:125-127, :386): [1 or R, sum of Cout] f32."""
+    B_, mc = self.buf, self._model_channels
     f32 = torch.float32
-    self._gnp = B_.get("gn_partial", (R * 128 * 32 * 2,), f32)
-    # timestep embedding + MLP + all temb projections (unet.py:125-127, :386)
     rt = 1 if (index is not None or shared_t) else R
     emb = B_.get("temb_sin", (rt, mc), f32)
     if index is not None:
@@ -472,21 +547,46 @@ class UNet:
     ops.gemv(th, self.time2[0], self.time2[1], temb)
     tall = B_.get("temb_all", (rt, self.temb_total), f32)
     ops.gemv(temb, self.temb_all[0], self.temb_all[1], tall, act_in=ops.ACT_SILU)
+    return tall
 
+  def _env(self, x, tall, out):
+    """The evaluation as a flat program over buffers every branch shares: the skip / concat buffers `cats`
+    (cat[j] = input of output block j = [previous output | skip n_in - j]), the final feature map, x, out.
+    A step is (kind, index, level); a branch executes a range of steps on its row slice of these buffers."""
+    R, h, w, _ = x.shape
+    B_, dt, mc = self.buf, self.dtype, self._model_channels
     n_in = len(self.in_blocks)
-    # cat[j]: input of output block j = [previous output | skip n_in - j]
     prev_ch = [self.mid[2].cout] + [b[0].cout for b in self.out_blocks[:-1]]
     cats = []
     for j in range(len(self.out_blocks)):
       i = n_in - j
       lv = self.skip_lvl[i]
       cats.append(B_.get(f"cat{j}", (R, h >> lv, w >> lv, prev_ch[j] + self.skip_ch[i]), dt))
-    skip_dst = lambda i: cats[n_in - i][..., prev_ch[n_in - i]:]
+    final = B_.get("final", (R, h, w, self.out_blocks[-1][0].cout), dt)
+    prog = [("conv_in", 0, 0)]
+    for i in range(n_in):
+      prog.append(("in", i, self.skip_lvl[i + 1]))
+    top = max(self.skip_lvl)
+    prog.append(("mid", 0, top))
+    for j in range(len(self.out_blocks)):
+      prog.append(("out", j, self.skip_lvl[n_in - j]))
+    prog.append(("final", 0, 0))
+    return dict(x=x, tall=tall, out=out, cats=cats, final=final, prev_ch=prev_ch, prog=prog)
 
-    cur = skip_dst(0)
-    ops.conv3x3_small(x, self.conv_in[0], self.conv_in[1], cur)
-    for i, blk in enumerate(self.in_blocks):
-      dst = skip_dst(i + 1)
+  def _exec(self, env, step, rows):
+    kind, idx, _ = step
+    B_, dt = self.buf, self.dtype
+    sl = (lambda t: t) if rows is None else (lambda t: t[rows])
+    x, out, cats, prev_ch = sl(env["x"]), sl(env["out"]), env["cats"], env["prev_ch"]
+    tall = env["tall"] if env["tall"].shape[0] == 1 else sl(env["tall"])
+    R = x.shape[0]
+    n_in = len(self.in_blocks)
+    skip_dst = lambda i: sl(cats[n_in - i])[..., prev_ch[n_in - i]:]
+    if kind == "conv_in":
+      ops.conv3x3_small(x, self.conv_in[0], self.conv_in[1], skip_dst(0))
+    elif kind == "in":
+      cur, dst = skip_dst(idx), skip_dst(idx + 1)
+      blk = self.in_blocks[idx]
       if blk[0] == "down":
         self._conv_deferred(cur, blk[1], dst, bias=blk[2], stride=2)     # (flushes first: it reads cur)
       else:
@@ -497,22 +597,20 @@ class UNet:
           tmp = B_.get("blk_r", (R,) + tuple(dst.shape[1:3]) + (r.cout,), dt)
           self._res(r, cur, tall, tmp)
           self._st(st, tmp, dst)
-      cur = dst
-    r1, stm, r2 = self.mid
-    shp = (R,) + tuple(cur.shape[1:3]) + (r1.cout,)
-    m1 = self._res(r1, cur, tall, B_.get("blk_r", shp, dt))
-    m2 = self._st(stm, m1, B_.get("blk_s", shp, dt))
-    self._res(r2, m2, tall, cats[0][..., :r2.cout])
-    final = None
-    for j, (r, st, up) in enumerate(self.out_blocks):
-      xin = cats[j]
+    elif kind == "mid":
+      cur = skip_dst(n_in)
+      r1, stm, r2 = self.mid
+      shp = (R,) + tuple(cur.shape[1:3]) + (r1.cout,)
+      m1 = self._res(r1, cur, tall, B_.get("blk_r", shp, dt))
+      m2 = self._st(stm, m1, B_.get("blk_s", shp, dt))
+      self._res(r2, m2, tall, sl(cats[0])[..., :r2.cout])
+    elif kind == "out":
+      j = idx
+      r, st, up = self.out_blocks[j]
+      xin = sl(cats[j])
       hh, ww = xin.shape[1], xin.shape[2]
       last = j + 1 == len(self.out_blocks)
-      if last:
-        final = B_.get("final", (R, hh, ww, r.cout), dt)
-        dst = final
-      else:
-        dst = cats[j + 1][..., :r.cout]
+      dst = sl(env["final"]) if last else sl(cats[j + 1])[..., :r.cout]
       stages = 1 + (st is not None) + (up is not None)
       o = self._res(r, xin, tall, dst if stages == 1 else B_.get("blk_r", (R, hh, ww, r.cout), dt))
       if st is not None:
@@ -521,15 +619,14 @@ class UNet:
       if up is not None:
         self._flush()                                           # it reads o
         ops.conv3x3(o, up[0], dst, bias=up[1], upsample=True)   # unet.py:44-47
-    t0 = B_.get("gn", tuple(final.shape), dt)
-    self._gn(final, self.gn_out, GN_EPS_RES, True, t0)
-    if out is None:
-      out = torch.empty(R, h, w, self._out_channels, dtype=f32, device=self.device)
-    if self.conv_out_mm is not None:
-      ops.conv3x3(t0, self.conv_out_mm, out, bias=self.conv_out[1])
     else:
-      ops.conv3x3_small(t0, self.conv_out[0], self.conv_out[1], out)
-    return out
+      final = sl(env["final"])
+      t0 = B_.get("gn", tuple(final.shape), dt)
+      self._gn(final, self.gn_out, GN_EPS_RES, True, t0)
+      if self.conv_out_mm is not None:
+        ops.conv3x3(t0, self.conv_out_mm, out, bias=self.conv_out[1])
+      else:
+        ops.conv3x3_small(t0, self.conv_out[0], self.conv_out[1], out)
 
   def __call__(self, inputs, time, context=None, y=None, training=False):
     """unet.py:118 contract: inputs [R,h,w,4], time int [R], context [R,T,D]."""
