@@ -25,8 +25,9 @@
  * mutable datum is the thread-local last-error string) and never synchronises, so there is
  * nothing for a handle to hold and nothing for a *_sync to wait on: the caller synchronises its
  * own stream.  Re-entrancy follows from that: concurrent calls on different streams are safe as
- * long as they do not share caller-owned scratch.  Environment variables are consulted only by
- * A/B switches for the tools (read once per process), never for results.
+ * long as they do not share caller-owned scratch.  The library reads NO environment variable (the
+ * timing ablations and A/B switches of the tools exist only in the separate tools build,
+ * -DLDM_TOOLS_BUILD, which the product never loads).
  */
 #ifndef LDM_HIP_H
 #define LDM_HIP_H

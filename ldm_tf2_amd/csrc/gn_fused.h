@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NT, (SK ? (NT >= 1024 ? 4 : 2) : (MAXCH <= 8 || (MA
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
         kval[k] = active && (pl + (k0 + k) * P < HW);
-        koff[k] = kval[k] ? (int64_t)(k0 + k) * kstep : (active ? 0 : -(row0 * sk.N + c0));
+        koff[k] = kval[k] ? (int64_t)(k0 + k) * kstep : ((active && pl < HW) ? 0 : -(row0 * sk.N + c0));   // (pl >= HW: no chunk of mine is in range)
 #pragma unroll
         for (int e = 0; e < EPC; ++e) f[k][e] = 0.f;
         u32x4 z = {0u, 0u, 0u, 0u};

@@ -40,8 +40,12 @@ def test_two_rank_bench_equals_single_process_runs(dev, tmp_path):
   # two ranks, one device, gloo
   env2 = dict(base_env, LDM_DIST_BACKEND="gloo", LDM_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
   both = tmp_path / "both.npy"
+  import socket
+  with socket.socket() as sk:               # a free rendezvous port (a leftover child of an earlier run may hold a fixed one)
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
   j2 = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-             "--master-addr", "127.0.0.1", "--master-port", "29677", bench, "--gpus", "2",
+             "--master-addr", "127.0.0.1", "--master-port", str(port), bench, "--gpus", "2",
              "--dump-images", str(both)] + COMMON, env2)
   assert j2["world_size"] == 2 and j2["n_gpus"] == 2 and j2["backend"] == "gloo"
   assert j2["scaling"] == "weak" and j2["config"]["global_batch"] == 4

@@ -131,7 +131,8 @@ def test_unet_with_folded_layernorm_matches_the_oracle_and_the_unfolded_unet(dev
 # ---- split-K reduce fused into the consuming GroupNorm (ldm_groupnorm_splitk) ---------------------
 @pytest.mark.parametrize("dtype", [torch.float32, BF], ids=["f32", "bf16"])
 @pytest.mark.parametrize("B,H,Cin,Cout,split", [(4, 8, 128, 320, 3), (2, 16, 64, 640, 2), (3, 4, 256, 1280, 4),
-                                                (2, 8, 128, 960, 3)])
+                                                (2, 8, 128, 960, 3),
+                                                (2, 4, 128, 1280, 4)])      # HW = 16 < the rows a workgroup's threads span
 def test_splitk_reduce_fused_into_groupnorm(dev, dtype, B, H, Cin, Cout, split):
   """conv3x3 (split-K, + bias + per-sample addend + residual) -> GroupNorm + SiLU.  The fused launch gives
   the SAME bits as reduce-then-GroupNorm (same summation order), for the stored product and for the
