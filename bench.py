@@ -41,6 +41,11 @@ GF_UNET_ROW = {32: 182.48, 64: 809.54}
 GF_CONV_ROW = {32: 100.1, 64: 400.4}
 GF_GEMM_ROW = {32: 73.5, 64: 279.3}   # 64: token GEMMs x4, context K/V unchanged
 GF_CTX_KV_ROW = 4.9          # cross-attention K/V GEMMs, hoisted out of the step (step-invariant)
+# the CFG pair's common prefix (UNet.forward(paired_rows=True)): the first ResBlock's two 320 -> 320 convolutions and
+# the first transformer block's proj_in / q / k / v projections are evaluated for HALF the rows -- the family's
+# executed work is smaller by this much per skipped row (the roofline leg prices executed, not algorithmic, FLOPs)
+GF_PAIR_PREFIX_ROW = {32: 2 * 1024 * 2 * 9 * 320 * 320 / 1e9 + 4 * 1024 * 2 * 320 * 320 / 1e9}
+GF_PAIR_PREFIX_ROW[64] = 4 * GF_PAIR_PREFIX_ROW[32]
 GF_DECODE = {32: 623.11, 64: 2518.3}
 GF_TEXT_ROW = 77.96
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md: dense MFMA peaks
@@ -360,6 +365,9 @@ def main():
   lat = args.latent
   gf_family = ((GF_CONV_ROW.get(lat, 0) + GF_GEMM_ROW.get(lat, 0) - GF_CTX_KV_ROW) * R
                if lat in GF_CONV_ROW and not args.tiny else None)
+  gf_pair_skipped = GF_PAIR_PREFIX_ROW.get(lat, 0.0) * (R // 2) if getattr(unet, "_shared_prefix", False) else 0.0
+  if gf_family:
+    gf_family -= gf_pair_skipped
   roofline = None
   if gf_family:
     achieved = gf_family / gemm_ms          # GFLOP / ms = TFLOP/s
@@ -384,7 +392,8 @@ def main():
                 "avg_launch_us": gemm_ms * 1e3 / max(n_launches, 1),
                 "ms_unet_step_graph_full": t_full, "ms_unet_step_graph_without_family": t_rest,
                 "ms_per_unet_step_event_brackets": bracket_ms,
-                "algorithmic_gflop_per_unet_step": gf_family}
+                "algorithmic_gflop_per_unet_step": gf_family,
+                "gflop_not_executed_cfg_pair_prefix": gf_pair_skipped}
 
   if rank == 0 and args.dump_images:
     np.save(args.dump_images, out.cpu().numpy())

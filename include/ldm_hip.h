@@ -311,12 +311,16 @@ int ldm_st_xtail(const void* q, int64_t ldq, int K0, const void* ctx_k, const vo
  * [K0][C] gamma-folded with the attention scale * log2(e) and the padded rows of ldm_attention_ms's layout, qcs its
  * column sums, qb the folded bias: layout.ln_fold) run first; h1 is the residual of the second o-projection.  One
  * launch from the self-attention's output to the SpatialTransformer's output; `out` doubles as scratch for h1 and
- * must not alias an input. */
+ * must not alias an input.
+ * `in_rows` (0 or M: off; else M / 2): att, r0 and r1 hold only the first in_rows rows and output row m >= in_rows
+ * reads input row m - in_rows -- the classifier-free-guidance pair of the DDIM loop (model_runners.py:449-452 runs
+ * the U-Net on concat([xt, xt]): in front of the first cross-attention both halves of the batch are the same
+ * numbers, so the launches that feed this one ran once, on half the rows; ctx_k / ctx_vt cover all M / T samples). */
 int ldm_st_block(const void* att, int64_t lda, int K0, const void* wo1, const float* bo1, const void* r0, int64_t ldr0,
                  const void* wq, const float* qcs, const float* qb, const void* ctx_k, const void* ctx_vt, int Tk,
                  int ldv, int T, const void* wo2, const float* bo2, const void* w1, const float* aux, const void* w2,
                  const float* b2, const void* wp, const float* bp, const void* r1, int64_t ldr1, void* out, int64_t ldo,
-                 int M, int C, float eps, int dtype, void* stream);
+                 int M, int in_rows, int C, float eps, int dtype, void* stream);
 int ldm_ffn_geglu_supported(int M, int C, int dtype);
 int ldm_ffn_geglu(const void* x, int64_t ldx, const void* w1, const float* aux, const void* w2,
                   const float* b2, void* out, int64_t ldo, int M, int C, float eps, int dtype, void* stream);

@@ -77,8 +77,8 @@ SIGNATURES = {
     "ldm_st_xtail": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp,
                              c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "ldm_st_block": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32,
-                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_f32,
-                             c_i32, c_vp]),
+                             c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32, c_i32,
+                             c_f32, c_i32, c_vp]),
     "ldm_ffn_geglu_supported": (c_i32, [c_i32, c_i32, c_i32]),
     "ldm_ffn_geglu": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "ldm_time_embedding": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),

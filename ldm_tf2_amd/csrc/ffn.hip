@@ -90,6 +90,11 @@ struct FfnArgs {
   const char* ctx_k;
   const char* ctx_vt;
   int Tk, ldv, T;      // keys per sample, V^T row stride, query rows per sample (multiple of 128)
+  // The INPUT row tensors (x, r0, r1) may hold only the first `in_rows` rows of the panel range: output row m then
+  // reads input row m - in_rows (m >= in_rows).  This is the classifier-free-guidance pair of the DDIM loop
+  // (model_runners.py:449-452: the U-Net runs on concat([xt, xt])): until the first cross-attention the two halves
+  // of the batch are the same numbers, so everything in front of this launch ran once, on half the rows.
+  int in_rows;
 #ifdef LDM_TOOLS_BUILD
   int dbg;             // timing ablations (tools build only): 1 no MFMA, 2 no weight staging, 4 no GEGLU epilogue, 8 no B fragment reads
 #endif
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int m = m0 + srow[h];
-      xo[h] = m < p.M ? (uint32_t)((int64_t)m * p.ldx * 2) + sck[h] : kOOBf;
+      xo[h] = m < p.M ? (uint32_t)((int64_t)(m >= p.in_rows ? m - p.in_rows : m) * p.ldx * 2) + sck[h] : kOOBf;
     }
 #pragma unroll
     for (int kt = 0; kt < KTP; ++kt)
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
       for (int i = 0; i < TM; ++i) {
         const int row = RW * wm + 16 * i + lr;
         const int m = min(m0 + row, p.M - 1);
-        const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)m * p.ldr0;
+        const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)(m >= p.in_rows ? m - p.in_rows : m) * p.ldr0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
@@ -642,7 +647,7 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
       for (int i = 0; i < TM; ++i) {
         const int row = RW * wm + 16 * i + lr;
         const int m = min(m0 + row, p.M - 1);
-        const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)m * p.ldr0;
+        const bf16_t* rr = (const bf16_t*)p.r0 + (int64_t)(FRONT ? m : (m >= p.in_rows ? m - p.in_rows : m)) * p.ldr0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
@@ -792,7 +797,7 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
         const int n = 128 * pp + 64 * wn + 16 * j + 4 * lh;
         const f32x4 bb = *(const f32x4*)((POST ? p.bp : p.b2) + n);
         u32x2 rv;
-        if constexpr (POST) rv = *(const u32x2*)((const bf16_t*)p.r1 + (int64_t)m * p.ldr1 + n);
+        if constexpr (POST) rv = *(const u32x2*)((const bf16_t*)p.r1 + (int64_t)(m >= p.in_rows ? m - p.in_rows : m) * p.ldr1 + n);
         else rv = *(const u32x2*)panel_cell(row, n);
         float v[4];
 #pragma unroll
@@ -829,7 +834,7 @@ void fill_common(FfnArgs* a, const void* x, int64_t ldx, const void* w1, const f
   a->x_bytes = (uint32_t)((((int64_t)M - 1) * ldx + xcols) * 2);
   a->w1_bytes = (uint32_t)(8 * C * C * 2); a->w2_bytes = (uint32_t)(C * 4 * C * 2);
   a->aux_bytes = (uint32_t)(8 * C / 128 * 1024);
-  a->M = M; a->eps = eps;
+  a->M = M; a->eps = eps; a->in_rows = M;
 #ifdef LDM_TOOLS_BUILD
   { static const int dbg = getenv("LDM_FFN_DEBUG") ? atoi(getenv("LDM_FFN_DEBUG")) : 0; a->dbg = dbg; }
 #endif
@@ -903,9 +908,12 @@ extern "C" int ldm_st_block(const void* att, int64_t lda, int K0, const void* wo
                             int64_t ldr0, const void* wq, const float* qcs, const float* qb, const void* ctx_k,
                             const void* ctx_vt, int Tk, int ldv, int T, const void* wo2, const float* bo2,
                             const void* w1, const float* aux, const void* w2, const float* b2, const void* wp,
-                            const float* bp, const void* r1, int64_t ldr1, void* out, int64_t ldo, int M, int C,
-                            float eps, int dtype, void* stream) {
-  int st = check_common("ldm_st_block", att, lda, w1, aux, w2, b2, out, ldo, M, C, K0, eps, dtype);
+                            const float* bp, const void* r1, int64_t ldr1, void* out, int64_t ldo, int M, int in_rows,
+                            int C, float eps, int dtype, void* stream) {
+  if (in_rows <= 0) in_rows = M;
+  LDM_CHECK_ARG(in_rows == M || (in_rows % 128 == 0 && M == 2 * in_rows && T > 0 && in_rows % T == 0),
+                "ldm_st_block: in_rows=%d must be M or M / 2 (whole 128-row panels, whole samples), M=%d", in_rows, M);
+  int st = check_common("ldm_st_block", att, lda, w1, aux, w2, b2, out, ldo, in_rows, C, K0, eps, dtype);
   if (st) return st;
   LDM_CHECK_ARG(K0 == 384, "ldm_st_block: attention width K0 = 384 (8 heads of 40 padded to 48) only, got %d", K0);
   LDM_CHECK_ARG(wo1 && bo1 && r0 && wq && qcs && qb && wo2 && bo2 && wp && bp && r1 && ctx_k && ctx_vt, "ldm_st_block: null pointer");
@@ -919,7 +927,8 @@ extern "C" int ldm_st_block(const void* att, int64_t lda, int K0, const void* wo
   LDM_CHECK_ARG((((int64_t)M - 1) * ldo + C) * 2 < (1ll << 31), "ldm_st_block: output extent must be < 2 GiB");
   LDM_CHECK_ARG(out != r0 && out != r1 && out != att, "ldm_st_block: out is also scratch, it must not alias an input");
   FfnArgs a;
-  fill_common(&a, att, lda, w1, aux, w2, b2, out, ldo, M, C, K0, eps);
+  fill_common(&a, att, lda, w1, aux, w2, b2, out, ldo, in_rows, C, K0, eps);     // (x extent: in_rows rows)
+  a.M = M; a.in_rows = in_rows;
   a.fw = (const char*)wo1; a.fb = bo1; a.r0 = (const char*)r0; a.ldr0 = ldr0; a.fw_bytes = (uint32_t)(C * K0 * 2);
   a.qw = (const char*)wq; a.qcs = qcs; a.qb = qb; a.qw_bytes = (uint32_t)(K0 * C * 2);
   a.out_bytes = (uint32_t)((((int64_t)M - 1) * ldo + C) * 2);

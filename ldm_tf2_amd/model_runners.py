@@ -169,7 +169,8 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
 
   def _step(self, guidance_scale, clip_denoised, noise_table, dec_index):
     """unet([xt; xt], t=steps[index]) -> CFG -> DDIM update, all on device."""
-    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps)
+    # (paired_rows: x2 = [xt; xt], one timestep -- rows r and r + B differ only in their context, :449-452)
+    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True)
     stride = 0 if noise_table is None else noise_table[0].numel()
     ops.cfg_ddim_update(self._eps, self._xt, self._xt, self._coef_dev, self._index_dev,
                         guidance_scale, noise=noise_table, x_unet_out=self._x2,
@@ -192,7 +193,7 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
       nz = torch.as_tensor(noise, dtype=torch.float32).to(self.device).contiguous()[None]
     pred_x0 = torch.empty_like(self._xt) if return_pred_x0 else None
     sample = torch.empty_like(self._xt)
-    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps)
+    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True)
     ops.cfg_ddim_update(self._eps, self._xt, sample, self._coef_dev, self._index_dev,
                         guidance_scale, noise=nz, x_unet_out=None, dec_index=False,
                         clip_denoised=clip_denoised, noise_index_stride=0, pred_x0_out=pred_x0)
@@ -322,7 +323,7 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
     x0_prog = torch.zeros_like(sample_prog)
     pred_x0 = torch.empty_like(self._xt)
     for index in range(n - 1, -1, -1):
-      self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps)
+      self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True)
       ops.cfg_ddim_update(self._eps, self._xt, self._xt, self._coef_dev, self._index_dev,
                           guidance_scale, noise=noise_table, x_unet_out=self._x2, dec_index=True,
                           clip_denoised=False, noise_index_stride=stride, pred_x0_out=pred_x0)

@@ -748,10 +748,14 @@ def st_xtail(q, ctx_k, ctx_vt, wo, bo, r0, w1, aux, w2, b2, wp, bp, r1, out, eps
 def st_block(att, wo1, bo1, r0, wq, qcs, qb, ctx_k, ctx_vt, wo2, bo2, w1, aux, w2, b2, wp, bp, r1, out, eps):
   """From the self-attention's output to the SpatialTransformer's output in ONE launch (ldm_st_block): o-projection
   + residual r0, LayerNorm-folded query projection, cross-attention against ctx_k / ctx_vt, o-projection + residual,
-  feed-forward, proj_out + residual r1.  att [R, T, 384]; layouts as st_xtail / linear(ln_fold=...)."""
+  feed-forward, proj_out + residual r1.  att [R, T, 384]; layouts as st_xtail / linear(ln_fold=...).
+  `out` / the context may cover TWICE the rows of att / r0 / r1 (a classifier-free-guidance pair whose two halves
+  are still identical in front of this launch): output row m >= R T reads input row m - R T."""
   Cc, K0 = out.shape[-1], att.shape[-1]
-  R, T = att.shape[0], att.shape[1]
+  Rin, T = att.shape[0], att.shape[1]
+  R = ctx_k.shape[0]
   M = R * T
+  assert R in (Rin, 2 * Rin) and r0.numel() // Cc == Rin * T and r1.numel() // Cc == Rin * T
   assert att.dim() == 3 and att.is_contiguous() and ctx_k.is_contiguous() and ctx_vt.is_contiguous()
   assert ctx_k.shape[0] == R and ctx_k.shape[2] == K0 and tuple(ctx_vt.shape[:2]) == (R, K0)
   assert out.numel() // Cc == M and att.dtype == out.dtype == r0.dtype == r1.dtype == ctx_k.dtype == ctx_vt.dtype
@@ -762,7 +766,7 @@ def st_block(att, wo1, bo1, r0, wq, qcs, qb, ctx_k, ctx_vt, wo2, bo2, w1, aux, w
   check(lib.ldm_st_block(_ptr(att), K0, K0, _ptr(wo1), _ptr(_f32(bo1, "bo1")), _ptr(r0), row_ld(r0), _ptr(wq), _ptr(qcs),
                          _ptr(_f32(qb, "qb")), _ptr(ctx_k), _ptr(ctx_vt), ctx_k.shape[1], ctx_vt.shape[2], T, _ptr(wo2),
                          _ptr(_f32(bo2, "bo2")), _ptr(w1), _ptr(aux), _ptr(w2), _ptr(_f32(b2, "b2")), _ptr(wp),
-                         _ptr(_f32(bp, "bp")), _ptr(r1), row_ld(r1), _ptr(out), row_ld(out), M, Cc, float(eps),
+                         _ptr(_f32(bp, "bp")), _ptr(r1), row_ld(r1), _ptr(out), row_ld(out), M, Rin * T, Cc, float(eps),
                          code(out.dtype), _stream()), "ldm_st_block")
   return out
 

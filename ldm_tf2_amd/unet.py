@@ -123,7 +123,7 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None):
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -161,6 +161,7 @@ class UNet:
     # its own scratch and split-K workspace -- ONE fork after the timestep MLP, ONE join before the caller's
     # next launch -- so one branch's latency-bound launches run beside the other's convolutions.  Each
     # branch runs the launch plans of ITS row count.
+    self._shared_prefix = bool(shared_prefix)     # forward(paired_rows=True): the CFG pair's common prefix once (A/B: False)
     self._lanes = max(1, int(lanes))
     # lane_levels = L: only the levels from L down (the downsample conv into level L .. the upsample conv out of it)
     # are branched, the full-resolution levels run unbranched on all rows; None: the whole evaluation
@@ -356,7 +357,17 @@ class UNet:
     self._conv_deferred(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
     return out
 
-  def _st(self, st, x, out):
+  def _dup_rows(self, t, tag):
+    """[t; t] along dim 0 (a CFG pair leaving its common prefix on a path without ldm_st_block's in_rows)."""
+    n = t.shape[0]
+    full = self.buf.get(tag, (2 * n,) + tuple(t.shape[1:]), t.dtype)
+    ops.cast(t, full[:n])
+    ops.cast(t, full[n:])
+    return full
+
+  def _st(self, st, x, out, pair=False):
+    """`pair`: x holds the first half of out's rows and the second half is identical up to the first
+    cross-attention (forward(paired_rows=True)); out and the context cover all rows."""
     B_, dt = self.buf, self.dtype
     R, h, w, c = x.shape
     T, hs = h * w, st.heads * st.sp
@@ -397,17 +408,26 @@ class UNet:
     att = B_.get("st_att", (R, T, hs), dt)
     ms = fold is not None and st.ms
     ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
-    hb = B_.get("st_b", (R, T, c), dt)
-    q = B_.get("st_q", (R, T, hs), dt)
-    panel = (fold is not None and st.ffn_aux is not None and self._fused_ffn and R * T >= self._ffn_min_rows)
     ctx_k, ctx_vt = (st.ctx_k, st.ctx_vt) if self._rows is None else (st.ctx_k[self._rows], st.ctx_vt[self._rows])
+    Ro = ctx_k.shape[0]                   # rows of `out` (= 2 R for a pair)
+    assert Ro == (2 * R if pair else R) and out.shape[0] == Ro
+    panel = (fold is not None and st.ffn_aux is not None and self._fused_ffn and Ro * T >= self._ffn_min_rows)
     xtail = (panel and self._fused_tail and self._fused_xattn and ms and hs == 384 and T % 128 == 0
              and ctx_k.shape[1] <= 80 and ctx_vt.shape[2] >= 80)
+    if pair and not (xtail and self._fused_block):
+      # per-layer path: the pair leaves its common prefix here -- both halves get their copy of the self-attention's
+      # output, the residual stream and the block input, and everything below covers all rows
+      att, ha, x = self._dup_rows(att, "st_att_pair"), self._dup_rows(ha, "st_a_pair"), self._dup_rows(x, "st_x_pair")
+      R = Ro
+      ln = B_.get("st_ln", (R, T, c), dt)
+      lnp = lambda i: (st.ln[i][0], st.ln[i][1], ln, LN_EPS) if fuse_ln else None
+    hb = B_.get("st_b", (R, T, c), dt)
+    q = B_.get("st_q", (R, T, hs), dt)
     if xtail and self._fused_block:
       # everything from the self-attention's output to the block's output: ONE row-panel launch (ldm_st_block)
       ops.st_block(att, st.o1[0], st.o1[1], ha, fold["q2"][0], fold["q2"][1], fold["q2"][2], ctx_k, ctx_vt,
                    st.o2[0], st.o2[1], fold["geglu"][0], st.ffn_aux, st.ff_out[0], st.ff_out[1], st.proj_out[0],
-                   st.proj_out[1], x, out, LN_EPS)
+                   st.proj_out[1], x, out, LN_EPS)      # (pair: att / ha / x hold half of out's rows -> in_rows)
       return out
     ops.linear(att, st.o1[0], hb, bias=st.o1[1], residual=ha, ln=lnp(1))
     # cross-attention (unet.py:311-312)
@@ -450,10 +470,15 @@ class UNet:
     return out
 
   # ---- forward ---------------------------------------------------------------------------------
-  def forward(self, x, t_rows=None, steps=None, index=None, out=None, shared_t=False):
+  def forward(self, x, t_rows=None, steps=None, index=None, out=None, shared_t=False, paired_rows=False):
     """x f32 [R,h,w,4].  Timestep either per row (`t_rows` int32 [R]) or, for the
     graph-replayed DDIM loop, `steps[*index]` for every row.  `shared_t=True` with
-    t_rows declares that all rows carry t_rows[0]."""
+    t_rows declares that all rows carry t_rows[0].
+    `paired_rows=True` declares that rows r and r + R/2 carry the SAME x and t and differ only in their context
+    (the classifier-free-guidance batch concat([xt, xt]) of model_runners.py:449-452).  Nothing of the U-Net mixes
+    rows and the context first enters at the first cross-attention (unet.py:311), so the launches in front of it
+    -- the first ResBlock and the first transformer block up to its self-attention -- are the same numbers for both
+    halves: they run once, on R/2 rows (`shared_prefix`, bf16 and float32)."""
     assert x.dtype == torch.float32 and x.is_contiguous()
     R, h, w, _ = x.shape
     nlev = max(self.skip_lvl)
@@ -463,6 +488,8 @@ class UNet:
       out = torch.empty(R, h, w, self._out_channels, dtype=torch.float32, device=self.device)
     tall = self._temb(R, t_rows, steps, index, shared_t)
     env = self._env(x, tall, out)
+    env["pair"] = bool(paired_rows and self._shared_prefix and R % 2 == 0 and self._lanes == 1 and not self.fuse_groupnorm
+                       and self.in_blocks[0][0] == "res" and self.in_blocks[0][2] is not None)
     prog = env["prog"]
     n = self._lanes if (self._lanes > 1 and R % self._lanes == 0) else 1
     if n == 1:
@@ -593,6 +620,15 @@ class UNet:
         _, r, st = blk
         if st is None:
           self._res(r, cur, tall, dst)
+        elif idx == 0 and env.get("pair") and rows is None:
+          # the CFG pair's common prefix: ResBlock + the transformer block's head on the first R/2 rows, with the
+          # launch plans of THAT row count; the block's tail (from the first cross-attention on) on all rows
+          half = R // 2
+          self._flush()
+          with ops.plan_scope(half, x.shape[1], dt):
+            tmp = B_.get("blk_r_pair", (half,) + tuple(dst.shape[1:3]) + (r.cout,), dt)
+            self._res(r, cur[:half], tall if tall.shape[0] == 1 else tall[:half], tmp)
+            self._st(st, tmp, dst, pair=True)
         else:
           tmp = B_.get("blk_r", (R,) + tuple(dst.shape[1:3]) + (r.cout,), dt)
           self._res(r, cur, tall, tmp)

@@ -459,6 +459,18 @@ def test_st_block_from_self_attention_output_to_block_output(dev, R, T, Tk):
   print(f"st_block R={R} T={T} Tk={Tk}: rel {r:.3e} (2 GEMMs + st_xtail {r2:.3e}; fused vs those {d:.3e})")
   assert torch.isfinite(out.float()).all()
   assert r < 6e-3 and r <= r2 * 1.2 + 1e-4 and d < 3e-3
+  if R % 2 == 0:
+    # in_rows (round 4): a classifier-free-guidance pair -- att / r0 / r1 hold only the first half of the rows, the
+    # second half of the output reads the same input rows against ITS samples' context: the same bits as the launch
+    # on explicitly duplicated inputs
+    Rh, Mh = R // 2, M // 2
+    dup = lambda t_: torch.cat([t_[:t_.shape[0] // 2], t_[:t_.shape[0] // 2]], 0).contiguous()
+    out_d = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+    o.st_block(dup(ad), wo1, bo1d, dup(r0d), wq, qcs, qb, kd, vt, wo2, bo2d, w1, aux, w2, b2d, wp, bpd, dup(r1d), out_d, 1e-5)
+    out_p = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+    o.st_block(ad[:Rh].contiguous(), wo1, bo1d, r0d[:Mh].contiguous(), wq, qcs, qb, kd, vt, wo2, bo2d, w1, aux, w2, b2d,
+               wp, bpd, r1d[:Mh].contiguous(), out_p, 1e-5)
+    assert torch.equal(out_p, out_d) and torch.equal(out_p[:Mh], out[:Mh]) and not torch.equal(out_p[Mh:], out[Mh:])
 
 
 def test_st_block_at_the_benchmark_size_equals_the_per_layer_launches(dev):

@@ -35,7 +35,8 @@ def main():
   w = Wt.init_weights(Wt.unet_manifest(**cfg), seed=2, scope="unet")
   R = 2 * args.batch
   g = np.random.default_rng(0)
-  x = torch.from_numpy(g.standard_normal((R, args.latent, args.latent, 4)).astype(np.float32)).to(dev)
+  xh = g.standard_normal((args.batch, args.latent, args.latent, 4)).astype(np.float32)
+  x = torch.from_numpy(np.concatenate([xh, xh], 0)).to(dev)       # the DDIM loop's concat([xt, xt]) (model_runners.py:449)
   ctx = torch.from_numpy(g.standard_normal((R, 77, 1280)).astype(np.float32)).to(dev)
   t = torch.full((R,), 500, dtype=torch.int32, device=dev)
   graphs, names, outs = [], [], []
@@ -57,11 +58,11 @@ def main():
     unet = UNet(**cfg, weights=w, dtype=torch.bfloat16, device=dev, **kw)
     unet.set_context(ctx)
     out = torch.empty(R, args.latent, args.latent, 4, device=dev)
-    unet.forward(x, t_rows=t, out=out, shared_t=True)
+    unet.forward(x, t_rows=t, out=out, shared_t=True, paired_rows=True)
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
-      unet.forward(x, t_rows=t, out=out, shared_t=True)
+      unet.forward(x, t_rows=t, out=out, shared_t=True, paired_rows=True)
     for _ in range(3):
       gr.replay()
     torch.cuda.synchronize()
