@@ -339,6 +339,14 @@ int ldm_gemv(const float* x, int64_t ldx, const void* wt, const float* bias, flo
              int64_t ldy, int rows, int N, int K, int act_in, int act_out, int dtype,
              void* stream);
 
+/* out[0:cols] = table[i][0:cols] with i = *index, float32; `pre_decrement` != 0: i = --(*index) first.  The DDIM
+ * loop (model_runners.py:484-502) evaluates the timestep embedding, its MLP and the 22 ResBlock temb projections
+ * (unet.py:125-127, :386) -- functions of the step's t alone -- for ALL its steps once (a [N_steps][sum Cout] table)
+ * and each replayed step selects its row here; the same launch moves the device-resident loop counter (one
+ * workgroup: no launch may read *index while another moves it), so the step needs no decrement of its own. */
+int ldm_select_row(const float* table, int64_t ld, int rows, int cols, int32_t* index, int pre_decrement, float* out,
+                   void* stream);
+
 /*
  * Classifier-free guidance + DDIM update, float32 (model_runners.py:451-468):
  *   eps = eps_u + s*(eps_c - eps_u); x0 = c1*xt - c2*eps; mean = sqrt(a_prev)*x0

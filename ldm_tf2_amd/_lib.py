@@ -82,6 +82,7 @@ SIGNATURES = {
     "ldm_ffn_geglu_supported": (c_i32, [c_i32, c_i32, c_i32]),
     "ldm_ffn_geglu": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32, c_i32, c_vp]),
     "ldm_time_embedding": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "ldm_select_row": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "ldm_gemv": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32,
                          c_i32, c_i32, c_vp]),
     "ldm_cfg_ddim_update": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32,

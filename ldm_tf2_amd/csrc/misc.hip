@@ -281,6 +281,23 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* __restrict__
 // of the update kernel has read *index first
 __global__ void dec_index_kernel(int32_t* index) { *index = *index - 1; }
 
+// ---- out[:] = table[i][:], i = *index (pre_decrement: i = --*index first) --------------------------
+// ONE workgroup: the thread that moves the loop counter is in the same workgroup as every reader of it, so the
+// decrement needs no launch of its own, and every later launch of the step sees the new value.
+__global__ __launch_bounds__(1024) void select_row_kernel(const float* __restrict__ table, int64_t ld, int rows,
+                                                          int cols, int32_t* __restrict__ index, int pre_decrement,
+                                                          float* __restrict__ out) {
+  __shared__ int si;
+  if (threadIdx.x == 0) {
+    int i = *index;
+    if (pre_decrement) { i -= 1; *index = i; }
+    si = i < 0 ? 0 : (i >= rows ? rows - 1 : i);      // (a stray index reads a valid row; the loop never leaves the table)
+  }
+  __syncthreads();
+  const float* src = table + (int64_t)si * ld;
+  for (int c = threadIdx.x * 4; c < cols; c += 1024 * 4) *(f32x4*)(out + c) = *(const f32x4*)(src + c);
+}
+
 // ---- post_quant: out = Dense(latents / sf) ----------------------------------------
 template <typename TO>
 __global__ __launch_bounds__(256) void post_quant_kernel(const float* __restrict__ z, float sf,
@@ -548,6 +565,16 @@ extern "C" int ldm_cfg_ddim_update(const float* eps_all, const float* xt, const 
     st = ldm_launch_status("ldm_cfg_ddim_update(dec)");
   }
   return st;
+}
+
+extern "C" int ldm_select_row(const float* table, int64_t ld, int rows, int cols, int32_t* index, int pre_decrement,
+                              float* out, void* stream) {
+  LDM_CHECK_ARG(table && index && out && rows > 0 && cols > 0, "ldm_select_row: bad args");
+  LDM_CHECK_ARG(cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)table % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                "ldm_select_row: cols / ld must be multiples of 4 floats, table / out 16-byte aligned");
+  hipLaunchKernelGGL(select_row_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, table, ld, rows, cols, index,
+                     pre_decrement, out);
+  return ldm_launch_status("ldm_select_row");
 }
 
 extern "C" int ldm_post_quant(const float* latents, float scale_factor, const float* kernel_io,

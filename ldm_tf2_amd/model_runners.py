@@ -134,13 +134,33 @@ class LatentDiffusionModel(object):
 
 class LatentDiffusionModelSampler(LatentDiffusionModel):
 
-  def __init__(self, *args, use_graph=True, verbose=True, **kwargs):
+  def __init__(self, *args, use_graph=True, verbose=True, temb_table=True, **kwargs):
     super().__init__(*args, **kwargs)
     self._use_graph = use_graph
+    self._use_temb_table = bool(temb_table)      # A/B: False = four temb launches + a decrement launch per step
+    self._temb_tbl = None
+    self._pre_dec = False
     self._verbose = verbose
     self._graph = None
     self._graph_key = None
     self.last_step_ms = None
+
+  # ---- the steps' temb projections, once per sampler ---------------------------------
+  def _temb_kwargs(self, dec_index):
+    """kwargs of UNet.forward for one step: the table of every DDIM step's temb projections (built on first use: it
+    depends on the step table and the weights only) and whether the step's first launch moves the loop counter.
+    A U-Net without `temb_table` (any callable with the forward contract) gets neither."""
+    if self._temb_tbl is None and hasattr(self._unet, "temb_table") and self._use_temb_table:
+      self._temb_tbl = self._unet.temb_table(self._steps_dev).clone()     # (the U-Net's scratch may serve another sampler)
+    self._pre_dec = self._temb_tbl is not None
+    if self._temb_tbl is None:
+      return {}
+    return dict(temb_table=self._temb_tbl, pre_decrement=bool(dec_index))
+
+  def _loop_start_index(self, n):
+    """Value of the device-side counter before the first step: steps that pre-decrement start one above."""
+    self._temb_kwargs(True)
+    return n if self._pre_dec else n - 1
 
   # ---- one step on device state -----------------------------------------------------
   def _alloc_state(self, B, h, w, c):
@@ -167,14 +187,18 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
     buf.copy_(src)
     return buf
 
-  def _step(self, guidance_scale, clip_denoised, noise_table, dec_index):
+  def _step(self, guidance_scale, clip_denoised, noise_table, dec_index, pred_x0_out=None):
     """unet([xt; xt], t=steps[index]) -> CFG -> DDIM update, all on device."""
     # (paired_rows: x2 = [xt; xt], one timestep -- rows r and r + B differ only in their context, :449-452)
-    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True)
+    # The loop counter moves at the START of a step (`dec_index`: the U-Net's first launch pre-decrements it and
+    # selects the step's row of the temb table), so a loop starts from index = N and ends at 0.
+    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True,
+                       **self._temb_kwargs(dec_index))
     stride = 0 if noise_table is None else noise_table[0].numel()
     ops.cfg_ddim_update(self._eps, self._xt, self._xt, self._coef_dev, self._index_dev,
                         guidance_scale, noise=noise_table, x_unet_out=self._x2,
-                        dec_index=dec_index, clip_denoised=clip_denoised, noise_index_stride=stride)
+                        dec_index=dec_index and not self._pre_dec, clip_denoised=clip_denoised,
+                        noise_index_stride=stride, pred_x0_out=pred_x0_out)
 
   def ddim_sample(self, xt, cond, index, guidance_scale=1., clip_denoised=True,
                   return_pred_x0=False, noise=None):
@@ -193,7 +217,8 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
       nz = torch.as_tensor(noise, dtype=torch.float32).to(self.device).contiguous()[None]
     pred_x0 = torch.empty_like(self._xt) if return_pred_x0 else None
     sample = torch.empty_like(self._xt)
-    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True)
+    self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True,
+                       **self._temb_kwargs(False))
     ops.cfg_ddim_update(self._eps, self._xt, sample, self._coef_dev, self._index_dev,
                         guidance_scale, noise=nz, x_unet_out=None, dec_index=False,
                         clip_denoised=clip_denoised, noise_index_stride=0, pred_x0_out=pred_x0)
@@ -237,7 +262,7 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
     self._xt.copy_(xt)
     self._x2[:B].copy_(xt)
     self._x2[B:].copy_(xt)
-    self._index_dev.fill_(n - 1)                                          # :476
+    self._index_dev.fill_(self._loop_start_index(n))                      # :476 (index = N - 1 in the first step)
 
     gkey = (float(guidance_scale), noise_table is not None, self._ctx_shape)
     use_graph = self._use_graph and record is None
@@ -246,6 +271,7 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
     if use_graph:
       if self._graph is None or self._graph_key != gkey:
         # warm-up run on a side stream allocates every scratch buffer, then capture
+        self._index_dev.fill_(n - 1)                 # (the warm-up step does not move the counter)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -264,7 +290,7 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
         self._xt.copy_(xt)
         self._x2[:B].copy_(xt)
         self._x2[B:].copy_(xt)
-        self._index_dev.fill_(n - 1)
+        self._index_dev.fill_(self._loop_start_index(n))
       t0.record()
       for _ in range(n):                                                  # :484-502
         self._graph.replay()
@@ -317,16 +343,12 @@ class LatentDiffusionModelSampler(LatentDiffusionModel):
     self._xt.copy_(xt)
     self._x2[:B].copy_(xt)
     self._x2[B:].copy_(xt)
-    self._index_dev.fill_(n - 1)
-    stride = 0 if noise_table is None else noise_table[0].numel()
+    self._index_dev.fill_(self._loop_start_index(n))
     sample_prog = torch.zeros(B, num_records, h, w, c, dtype=torch.float32, device=self.device)
     x0_prog = torch.zeros_like(sample_prog)
     pred_x0 = torch.empty_like(self._xt)
     for index in range(n - 1, -1, -1):
-      self._unet.forward(self._x2, steps=self._steps_dev, index=self._index_dev, out=self._eps, paired_rows=True)
-      ops.cfg_ddim_update(self._eps, self._xt, self._xt, self._coef_dev, self._index_dev,
-                          guidance_scale, noise=noise_table, x_unet_out=self._x2, dec_index=True,
-                          clip_denoised=False, noise_index_stride=stride, pred_x0_out=pred_x0)
+      self._step(guidance_scale, False, noise_table, dec_index=True, pred_x0_out=pred_x0)
       r = index // record_freq
       if r < num_records:                      # later (smaller) indices overwrite the slot
         sample_prog[:, r].copy_(self._xt)

@@ -778,6 +778,16 @@ def time_embedding(out, channels, t_rows=None, steps=None, index=None):
   return out
 
 
+def select_row(table, index, out, pre_decrement=False):
+  """out[0, :] = table[*index, :] (float32); `pre_decrement`: *index is decremented first (the DDIM loop's
+  device-side counter moves in the step's first launch)."""
+  assert table.dim() == 2 and table.stride(1) == 1 and out.is_contiguous() and out.numel() == table.shape[1]
+  assert index.dtype == torch.int32
+  check(lib.ldm_select_row(_ptr(_f32(table, "table")), table.stride(0), table.shape[0], table.shape[1], _ptr(index),
+                           int(bool(pre_decrement)), _ptr(_f32(out, "out")), _stream()), "ldm_select_row")
+  return out
+
+
 def gemv(x, wt, bias, y, act_in=ACT_NONE, act_out=ACT_NONE):
   """y[r, n] = act_out(sum_k act_in(x[r, k]) wt[n, k] + bias[n]); x, y float32."""
   rows, K = x.shape

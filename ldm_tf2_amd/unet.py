@@ -470,7 +470,8 @@ class UNet:
     return out
 
   # ---- forward ---------------------------------------------------------------------------------
-  def forward(self, x, t_rows=None, steps=None, index=None, out=None, shared_t=False, paired_rows=False):
+  def forward(self, x, t_rows=None, steps=None, index=None, out=None, shared_t=False, paired_rows=False,
+              temb_table=None, pre_decrement=False):
     """x f32 [R,h,w,4].  Timestep either per row (`t_rows` int32 [R]) or, for the
     graph-replayed DDIM loop, `steps[*index]` for every row.  `shared_t=True` with
     t_rows declares that all rows carry t_rows[0].
@@ -478,7 +479,9 @@ class UNet:
     (the classifier-free-guidance batch concat([xt, xt]) of model_runners.py:449-452).  Nothing of the U-Net mixes
     rows and the context first enters at the first cross-attention (unet.py:311), so the launches in front of it
     -- the first ResBlock and the first transformer block up to its self-attention -- are the same numbers for both
-    halves: they run once, on R/2 rows (`shared_prefix`, bf16 and float32)."""
+    halves: they run once, on R/2 rows (`shared_prefix`, bf16 and float32).
+    `temb_table` (from `temb_table(steps)`) with `index`: the step's temb projections are row *index of that table
+    (one launch instead of four); `pre_decrement`: that launch first decrements *index, the DDIM loop's counter."""
     assert x.dtype == torch.float32 and x.is_contiguous()
     R, h, w, _ = x.shape
     nlev = max(self.skip_lvl)
@@ -486,7 +489,13 @@ class UNet:
     assert self.sts[0].ctx_k is not None and self._ctx_rows == R, "call set_context(context) first"
     if out is None:
       out = torch.empty(R, h, w, self._out_channels, dtype=torch.float32, device=self.device)
-    tall = self._temb(R, t_rows, steps, index, shared_t)
+    if temb_table is not None:
+      assert index is not None and temb_table.shape[1] == self.temb_total
+      tall = self.buf.get("temb_all", (1, self.temb_total), torch.float32)
+      ops.select_row(temb_table, index, tall, pre_decrement=pre_decrement)
+    else:
+      assert not pre_decrement
+      tall = self._temb(R, t_rows, steps, index, shared_t)
     env = self._env(x, tall, out)
     env["pair"] = bool(paired_rows and self._shared_prefix and R % 2 == 0 and self._lanes == 1 and not self.fuse_groupnorm
                        and self.in_blocks[0][0] == "res" and self.in_blocks[0][2] is not None)
@@ -558,21 +567,29 @@ class UNet:
       finally:
         self._flush()
 
-  def _temb(self, R, t_rows, steps, index, shared_t):
+  def temb_table(self, steps):
+    """[len(steps), sum of Cout] float32: the temb projections of every timestep in `steps` (int32, device) -- the
+    same launches, row by row the same arithmetic, as one evaluation makes for its own t (unet.py:125-127, :386).
+    The DDIM loop builds it once and hands it to every step (forward(temb_table=...))."""
+    n = steps.numel()
+    tall = self._temb(n, steps.to(torch.int32).contiguous(), None, None, False, tag="tbl")
+    return tall
+
+  def _temb(self, R, t_rows, steps, index, shared_t, tag=""):
     """timestep embedding + MLP + all temb projections (unet.py:125-127, :386): [1 or R, sum of Cout] f32."""
     B_, mc = self.buf, self._model_channels
     f32 = torch.float32
     rt = 1 if (index is not None or shared_t) else R
-    emb = B_.get("temb_sin", (rt, mc), f32)
+    emb = B_.get("temb_sin" + tag, (rt, mc), f32)
     if index is not None:
       ops.time_embedding(emb, mc, steps=steps, index=index)
     else:
       ops.time_embedding(emb, mc, t_rows=t_rows)
-    th = B_.get("temb_h", (rt, 4 * mc), f32)
+    th = B_.get("temb_h" + tag, (rt, 4 * mc), f32)
     ops.gemv(emb, self.time1[0], self.time1[1], th, act_out=ops.ACT_SILU)
-    temb = B_.get("temb", (rt, 4 * mc), f32)
+    temb = B_.get("temb" + tag, (rt, 4 * mc), f32)
     ops.gemv(th, self.time2[0], self.time2[1], temb)
-    tall = B_.get("temb_all", (rt, self.temb_total), f32)
+    tall = B_.get("temb_all" + tag, (rt, self.temb_total), f32)
     ops.gemv(temb, self.temb_all[0], self.temb_all[1], tall, act_in=ops.ACT_SILU)
     return tall
 

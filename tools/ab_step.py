@@ -44,10 +44,13 @@ def main():
     name, _, kws = spec.partition("=")
     kw = {}
     plans = None
+    temb = 1
     for item in filter(None, kws.split(",")):
       k, _, v = item.partition(":")
       if k == "plans":              # this variant's launch-plan table (a tuner output) instead of the packaged ones
         plans = v
+      elif k == "temb":             # the step's temb projections as one row-select from a per-loop table (1) or as four launches (0)
+        temb = int(v)
       else:
         kw[k] = int(v)
     ops.clear_plans()               # (a captured graph keeps the plans it was captured with)
@@ -58,11 +61,14 @@ def main():
     unet = UNet(**cfg, weights=w, dtype=torch.bfloat16, device=dev, **kw)
     unet.set_context(ctx)
     out = torch.empty(R, args.latent, args.latent, 4, device=dev)
-    unet.forward(x, t_rows=t, out=out, shared_t=True, paired_rows=True)
+    steps = torch.tensor([500], dtype=torch.int32, device=dev)
+    idx = torch.zeros(1, dtype=torch.int32, device=dev)
+    tkw = dict(steps=steps, index=idx, temb_table=unet.temb_table(steps).clone()) if temb else dict(t_rows=t, shared_t=True)
+    unet.forward(x, out=out, paired_rows=True, **tkw)
     torch.cuda.synchronize()
     gr = torch.cuda.CUDAGraph()
     with torch.cuda.graph(gr):
-      unet.forward(x, t_rows=t, out=out, shared_t=True, paired_rows=True)
+      unet.forward(x, out=out, paired_rows=True, **tkw)
     for _ in range(3):
       gr.replay()
     torch.cuda.synchronize()
