@@ -457,16 +457,21 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     // out2 with n_split == 0: the WHOLE product is stored transposed per group of rows2 rows (V^T)
     const bool trans = p->out2 != nullptr;
     const bool ln = p->ln_cs != nullptr;
+    // out2 with n_split > 0: the n-tiles from n_split on are stored transposed, the ones below row-major
+    // (q | k | V^T of the self-attention as one launch; LayerNorm-folded form only)
+    const bool nsplit_out = trans && p->n_split > 0;
     if (ln)
       LDM_CHECK_ARG(!p->conv && p->bias && al16(p->ln_cs) && p->ln_eps > 0.f && !p->addend && !p->residual,
                     "ldm_gemm: ln_cs (LayerNorm fold) needs plain rows, the folded bias, ln_eps > 0 and no addend / residual");
     if (trans)
-      LDM_CHECK_ARG(p->n_split == 0 && !p->conv && (!p->bias || ln) && !p->addend && !p->residual && p->act == LDM_ACT_NONE &&
+      LDM_CHECK_ARG((p->n_split == 0 || (ln && p->n_split % bn == 0 && p->n_split < p->N)) && !p->conv && (!p->bias || ln) &&
+                        !p->addend && !p->residual && p->act == LDM_ACT_NONE &&
                         p->rows2 > 0 && p->rows2 % 32 == 0 && p->M % p->rows2 == 0 && p->ld2 % 8 == 0 && p->stride2 % 8 == 0 &&
                         al16(p->out2),
-                    "ldm_gemm: tile %d transposed output needs n_split 0, a plain product, rows2 %% 32 == 0, ld2 / stride2 %% 8 == 0", cfg);
+                    "ldm_gemm: tile %d transposed output needs n_split 0 (or, LayerNorm-folded, whole n-tiles below it), a plain "
+                    "product, rows2 %% 32 == 0, ld2 / stride2 %% 8 == 0", cfg);
     LDM_CHECK_ARG(p->dtype == LDM_BF16 && p->out_dtype == LDM_BF16 && p->batch == 1 && p->ldc_n == 1 &&
-                      !p->ln_out && split <= 1 && p->N % bn == 0 && (trans || (p->ldc_m % 8 == 0 && al16(p->out))) &&
+                      !p->ln_out && split <= 1 && p->N % bn == 0 && ((trans && !nsplit_out) || (p->ldc_m % 8 == 0 && al16(p->out))) &&
                       (!p->residual || (p->ldr % 4 == 0 && al16(p->residual))) && (!p->bias || al16(p->bias)) &&
                       (!p->addend || (al16(p->addend) && p->add_ld % 4 == 0)),
                   "ldm_gemm: tile %d (persistent) needs bf16 in/out, batch 1, a row-major 16-byte-aligned output, "
@@ -494,11 +499,18 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     if (nsplit > g.ntiles) nsplit = g.ntiles;
     g.tiles_per_wg = cdiv(g.ntiles, nsplit);
     g.nsplit = cdiv(g.ntiles, g.tiles_per_wg);
+    if (nsplit_out) {
+      // a workgroup lies on ONE side of n_split: the same tiles per workgroup on both sides, rounded per side
+      g.ntiles1 = p->n_split / bn;
+      g.tiles_per_wg2 = g.tiles_per_wg;
+      g.nsplit1 = cdiv(g.ntiles1, g.tiles_per_wg);
+      g.nsplit = g.nsplit1 + cdiv(g.ntiles - g.ntiles1, g.tiles_per_wg2);
+    }
     dim3 grid3((unsigned)(g.panels * g.nsplit));
     hipStream_t s3 = (hipStream_t)stream;
-    g.out_t = (char*)p->out2; g.ld_t = p->ld2; g.stride_t = p->stride2; g.rows_t = p->rows2;
+    g.out_t = (char*)p->out2; g.ld_t = p->ld2; g.stride_t = p->stride2; g.rows_t = p->rows2; g.n_split = p->n_split;
     g.ln_cs = p->ln_cs; g.ln_eps = p->ln_eps;
-    const int epi = (trans ? (ln ? (kEpiTrans | kEpiBias) : kEpiTrans)
+    const int epi = (trans ? (ln ? (kEpiTrans | kEpiBias | (nsplit_out ? kEpiSplit : 0)) : kEpiTrans)
                            : epi_code(p->bias != nullptr, p->addend != nullptr, p->residual != nullptr, p->act)) | (ln ? kEpiLn : 0);
     bool ok;
     if (ln) ok = launch_gemm3_ln(bn / 32, epi, g, grid3, s3);

@@ -17,6 +17,13 @@ bool launch_gemm3_ln(int tn, int epi, const Gemm3Args& a, dim3 grid, hipStream_t
     hipLaunchKernelGGL((gemm3_kernel<4, 0, kGeglu>), grid, dim3(512), 0, s, a);
     return true;
   }
+  // q | k row-major and V^T transposed in ONE launch (EPI bit 7; 128-column n-tiles: n_split = 2 heads Sp)
+  constexpr int kSplit = kTrans | kEpiSplit;
+  if (epi == kSplit) {
+    if (tn != 4) return false;
+    hipLaunchKernelGGL((gemm3_kernel<4, 0, kSplit>), grid, dim3(512), 0, s, a);
+    return true;
+  }
   if (epi == kTrans) {
     if (tn == 5) hipLaunchKernelGGL((gemm3_kernel<5, 0, kTrans>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((gemm3_kernel<4, 0, kTrans>), grid, dim3(512), 0, s, a);

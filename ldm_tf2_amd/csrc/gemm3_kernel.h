@@ -44,6 +44,9 @@ struct Gemm3Args {
   char* out_t;        // transposed output (EPI bit 5): out_t[(m / rows_t) * stride_t + n * ld_t + m % rows_t]
   int64_t ld_t, stride_t;
   int rows_t;
+  int n_split;        // EPI bit 7: columns >= n_split (whole n-tiles) take the transposed store, relative to n_split
+  int ntiles1, nsplit1, tiles_per_wg2;   // ... n-tiles below n_split, workgroups per panel that walk them
+                                         // (tiles_per_wg each), n-tiles per workgroup on the transposed side
   const float* ln_cs; // EPI bit 6: column sums of the gamma-scaled weights (LayerNorm folded into the product)
   float ln_eps;
 #ifdef LDM_TOOLS_BUILD
@@ -71,13 +74,20 @@ struct Gemm3Args {
 //         the workgroup's first n-tile (one row per lane, v_dot2c_f32_bf16 against (1, 1) and against
 //         itself): no LayerNorm launch, no normalised copy of the rows in HBM.  Statistics are f32
 //         sums of the bf16 values (E[x^2] - mean^2, clamped at 0)
-constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4, kEpiTrans = 32, kEpiLn = 64;
+//   bit 7 SPLIT output (with bit 5): n-tiles below n_split store row-major into `out`, the n-tiles from n_split on
+//         transposed into out_t (column n - n_split): the self-attention's q | k and V^T projections -- two
+//         products over the same LayerNorm'ed rows -- as ONE launch (one round of workgroups, one fill / drain
+//         instead of two).  A WORKGROUP lies on one side of n_split: the kernel body is instantiated once per side
+//         and the workgroup picks its instance at the top (a per-n-tile switch inside one body kept both
+//         epilogues' temporaries alive across the pipeline loop: 256 registers + 92 B of scratch against 190)
+constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4, kEpiTrans = 32, kEpiLn = 64, kEpiSplit = 128;
 constexpr int epi_code(bool bias, bool add, bool res, int act) { return (bias ? 1 : 0) | (add ? 2 : 0) | (res ? 4 : 0) | (act << 3); }
 
 // BN = 32 * TN columns per n-tile; waves 4 (M) x 2 (N); wave tile 64 x (16 TN)
-template <int TN, int MODE, int EPI>
-__global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+// TR: this workgroup's n-tiles are stored transposed (EPI bit 5; with bit 7 the workgroups of the transposed side)
+template <int TN, int MODE, int EPI, bool TR>
+__device__ __forceinline__ void gemm3_body(const Gemm3Args& p, char* smem, const int panel, const int nt_begin, const int ntl) {
   constexpr int BM = 256, BN = 32 * TN, WM = 4, WN = 2, NW = 8;
   constexpr int WTM = 64, WTN = 16 * TN, TM = 4;
   constexpr int NIB = BN / 8;
@@ -91,23 +101,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   constexpr int LNX = (EPI & 64) ? NW * 64 * 8 : 0;
   static_assert(NSTAGE * STAGE + LNX <= 160 * 1024, "LDS");
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE + LNX];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-
-  int bid = blockIdx.x;
-  {
-    const int nwg = gridDim.x;
-    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
-    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-  }
-  const int panel = bid / p.nsplit, sp = bid - panel * p.nsplit;
-  const int nt_begin = sp * p.tiles_per_wg;
-  const int ntl = min(p.ntiles, nt_begin + p.tiles_per_wg) - nt_begin;   // n-tiles of this workgroup
-  if (ntl <= 0) return;                                                  // (whole workgroup: uniform)
   const int m0 = panel * BM;
   const int nk = p.ktiles;
   const int S = ntl * nk;                                                // pipeline steps
@@ -259,6 +257,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   // SIMD's matrix pipe in the middle of a period (the early half once its fragment reads are back,
   // the late half from the barrier on); sharing it evenly makes both finish together and leaves
   // the late half's fragment reads exposed at the end of the period.
+  constexpr bool SPLIT = (EPI & kEpiSplit) != 0;
   auto multiply = [&](int prio) {
     if (LDM_G3_DBG(p) & 4) return;
     if (prio) __builtin_amdgcn_s_setprio(3);
@@ -269,7 +268,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          if constexpr ((EPI & kEpiTrans) != 0)       // natural order: lane = column n, registers = 4 rows m
+          if constexpr (TR)                           // natural order: lane = column n, registers = 4 rows m
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[kg][i]),
                                                                 __builtin_bit_cast(bf16x8, fb[kg][j]), acc[i][j], 0, 0, 0);
           else
@@ -343,7 +342,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
       ln_mu = ln_s * ik;
       ln_r = rsqrtf(fmaxf(ln_q * ik - ln_mu * ln_mu, 0.f) + p.ln_eps);
     }
-    if constexpr ((EPI & kEpiTrans) != 0) {
+    if constexpr (TR) {
+      const int n_t = SPLIT ? n_w - p.n_split : n_w;         // column of out_t
       // Transposed store: the lane owns column n = n_w + 16 j + (l & 15) and rows 16 i + 4 g + r.  Two
       // row blocks (i, i+1) are exchanged with v_permlane16_swap (8 consecutive rows = 16 bytes per
       // lane), then moved so that the four pieces of 32 consecutive rows of ONE column sit in adjacent
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
           o[1] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s1[0]);
           o[2] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s0[1]);
           o[3] = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)s1[1]);
-          if (valid) *(u32x4*)(obase + (int64_t)(n_w + 16 * j + col2) * p.ld_t) = o;
+          if (valid) *(u32x4*)(obase + (int64_t)(n_t + 16 * j + col2) * p.ld_t) = o;
         }
       }
       return;
@@ -594,6 +594,39 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
     }
   }
   epilogue(ntl - 1);
+}
+#endif
+
+template <int TN, int MODE, int EPI>
+__global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = 256, BN = 32 * TN;
+  constexpr int LNX = (EPI & 64) ? 8 * 64 * 8 : 0;
+  __shared__ __attribute__((aligned(16))) char smem[3 * (BM + BN) * 128 + LNX];
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+  }
+  const int panel = bid / p.nsplit, sp = bid - panel * p.nsplit;
+  if constexpr ((EPI & kEpiSplit) != 0) {
+    // workgroups 0 .. nsplit1 - 1 of a panel walk the row-major n-tiles, the others the transposed ones
+    if (sp < p.nsplit1) {
+      const int nt_begin = sp * p.tiles_per_wg;
+      const int ntl = min(p.ntiles1, nt_begin + p.tiles_per_wg) - nt_begin;
+      if (ntl > 0) gemm3_body<TN, MODE, EPI, false>(p, smem, panel, nt_begin, ntl);
+    } else {
+      const int nt_begin = p.ntiles1 + (sp - p.nsplit1) * p.tiles_per_wg2;
+      const int ntl = min(p.ntiles, nt_begin + p.tiles_per_wg2) - nt_begin;
+      if (ntl > 0) gemm3_body<TN, MODE, EPI, true>(p, smem, panel, nt_begin, ntl);
+    }
+  } else {
+    const int nt_begin = sp * p.tiles_per_wg;
+    const int ntl = min(p.ntiles, nt_begin + p.tiles_per_wg) - nt_begin;   // n-tiles of this workgroup
+    if (ntl > 0)                                                           // (whole workgroup: uniform)
+      gemm3_body<TN, MODE, EPI, (EPI & kEpiTrans) != 0>(p, smem, panel, nt_begin, ntl);
+  }
 #endif
 }
 

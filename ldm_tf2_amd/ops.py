@@ -170,6 +170,8 @@ def plan_key(p) -> str:
       p.M, p.N, p.K, p.batch, p.conv, p.H, p.W, p.stride, p.upsample, p.no_lead_pad, p.act, p.dtype, p.out_dtype)
   if p.out2 and p.n_split == 0:
     key += " t1"            # whole product stored transposed (linear_t)
+  elif p.out2 and p.ln_cs:
+    key += " sp%d" % p.n_split   # q | k row-major + V^T transposed in one LayerNorm-folded launch
   if p.ln_cs:
     key += " ln1"           # LayerNorm of the rows folded in (persistent tiles only)
   return key

@@ -98,7 +98,12 @@ class _ST:
         v_ones = L.ms_ones(heads, sp)                             # V^T row 40 = 1
         q_scale = torch.full((hs,), c2)
         self.ms_kbias, self.ms_vbias = v_ones.to(dev), v_ones.clone().to(dev)     # cross-attention K / V of the context
+      v_f = L.split_kernel(w[a1 + "/value/kernel"], sp, f32, cpu)
       self.fold = dict(
+          # q | k | v as ONE launch (row-major q | k, V^T transposed: ldm_gemm out2 with n_split = 2 heads Sp)
+          qkv1=L.ln_fold(torch.cat([qk_f, v_f], 0), lnp[0][0], lnp[0][1], None, dtype, dev,
+                         row_scale=None if qk_scale is None else torch.cat([qk_scale, torch.ones(hs)]),
+                         bias_extra=None if qk_ones is None else torch.cat([qk_ones, v_ones])),
           qk1=L.ln_fold(qk_f, lnp[0][0], lnp[0][1], None, dtype, dev, row_scale=qk_scale, bias_extra=qk_ones),
           v1=L.ln_fold(L.split_kernel(w[a1 + "/value/kernel"], sp, f32, cpu), lnp[0][0], lnp[0][1], None, dtype, dev,
                        bias_extra=v_ones),
@@ -123,7 +128,7 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True):
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=16384):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -161,6 +166,10 @@ class UNet:
     # its own scratch and split-K workspace -- ONE fork after the timestep MLP, ONE join before the caller's
     # next launch -- so one branch's latency-bound launches run beside the other's convolutions.  Each
     # branch runs the launch plans of ITS row count.
+    self._merge_qkv = bool(merge_qkv)             # LayerNorm-folded q | k | V^T as one launch (A/B: False = two)
+    # ... where a panel's workgroups can be dealt to the two sides of the launch evenly: at M = 32768 (128 panels,
+    # 2 workgroups each for 6 + 3 n-tiles) the one-sided workgroups would be 6 and 3 tiles long
+    self._merge_qkv_max_rows = int(merge_qkv_max_rows)
     self._shared_prefix = bool(shared_prefix)     # forward(paired_rows=True): the CFG pair's common prefix once (A/B: False)
     self._lanes = max(1, int(lanes))
     # lane_levels = L: only the levels from L down (the downsample conv into level L .. the upsample conv out of it)
@@ -387,7 +396,10 @@ class UNet:
     # LayerNorm folded into its consumer (bf16, launches with enough rows for the persistent kernel)
     fold = st.fold if (st.fold is not None and R * T >= self._fold_min_rows and T % 32 == 0) else None
     # self-attention (unet.py:309-310)
-    if fold is not None:
+    if fold is not None and self._merge_qkv and R * T <= self._merge_qkv_max_rows and hs % 128 == 0:
+      # q | k | V^T: one pass of the persistent kernel over the LayerNorm'ed rows (gemm3_kernel EPI bit 7)
+      ops.linear(ha, fold["qkv1"][0], qk, bias=fold["qkv1"][2], ln_fold=(fold["qkv1"][1], LN_EPS), out2=vt)
+    elif fold is not None:
       ops.linear(ha, fold["qk1"][0], qk, bias=fold["qk1"][2], ln_fold=(fold["qk1"][1], LN_EPS))
       ops.linear_t(ha, fold["v1"][0], vt, bias=fold["v1"][2], ln_fold=(fold["v1"][1], LN_EPS))
     elif not fuse_ln:

@@ -226,6 +226,46 @@ def test_temb_table_loop_equals_the_per_step_launches(dev, unet_w):
       assert torch.equal(v[1], ref[1]) and torch.equal(v[0], ref[0]), f"{dtype} temb_table={k[0]} graph={k[1]} differs"
 
 
+@pytest.mark.parametrize("R,T,C,H,S", [(4, 256, 640, 8, 80), (4, 64, 1280, 8, 160), (2, 128, 640, 8, 80), (3, 96, 320, 8, 40)])
+def test_merged_qkv_launch_equals_the_two_launches(dev, R, T, C, H, S):
+  """LayerNorm -> q | k (row-major) and -> V^T (transposed per sample) as ONE launch of the persistent kernel
+  (ldm_gemm out2 with n_split = 2 heads Sp and ln_cs; unet.py:270-276, :309): the same bits as the two launches it
+  replaces (every output is the same sequence of MFMAs over k), and the oracle's LayerNorm + Dense within the bf16
+  gate.  The last case has 40-wide heads padded to 48 (n_split = 768: six 128-column n-tiles) and ragged rows."""
+  from ldm_tf2_amd import layout as L
+  BF = torch.bfloat16
+  g = torch.Generator().manual_seed(11)
+  sp = L.padded_head(S)
+  hs = H * sp
+  M = R * T
+  x = (torch.randn(M, C, generator=g) * 1.5 + 0.5 * torch.randn(M, 1, generator=g)).to(BF)
+  gamma, beta = 1.0 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+  kq, kk, kv = (torch.randn(C, H, S, generator=g).numpy() * C ** -0.5 for _ in range(3))
+  f32, cpu = torch.float32, "cpu"
+  wq, wk, wv = (L.split_kernel(k_, sp, f32, cpu) for k_ in (kq, kk, kv))
+  qk_w, qk_cs, qk_b = L.ln_fold(torch.cat([wq, wk], 0), gamma.numpy(), beta.numpy(), None, BF, dev)
+  v_w, v_cs, v_b = L.ln_fold(wv, gamma.numpy(), beta.numpy(), None, BF, dev)
+  a_w, a_cs, a_b = L.ln_fold(torch.cat([wq, wk, wv], 0), gamma.numpy(), beta.numpy(), None, BF, dev)
+  xd = x.to(dev).view(R, T, C)
+  tp = (T + 7) // 8 * 8
+  qk0 = torch.empty(R, T, 2 * hs, dtype=BF, device=dev)
+  vt0 = torch.zeros(R, hs, tp, dtype=BF, device=dev)
+  ops.linear(xd, qk_w, qk0, bias=qk_b, ln_fold=(qk_cs, 1e-5))
+  ops.linear_t(xd, v_w, vt0, bias=v_b, ln_fold=(v_cs, 1e-5))
+  qk1 = torch.full((R, T, 2 * hs), float("nan"), dtype=BF, device=dev)
+  vt1 = torch.zeros(R, hs, tp, dtype=BF, device=dev)
+  ops.linear(xd, a_w, qk1, bias=a_b, ln_fold=(a_cs, 1e-5), out2=vt1)
+  torch.cuda.synchronize()
+  assert torch.equal(qk1, qk0) and torch.equal(vt1, vt0)
+  ln = O.layer_norm(x.float(), gamma, beta, eps=1e-5)
+  want_qk = ln @ torch.cat([wq, wk], 0).t()
+  want_v = (ln @ wv.t()).view(R, T, hs).permute(0, 2, 1)
+  r1 = ((qk1.float().cpu().view(M, -1) - want_qk).norm() / want_qk.norm()).item()
+  r2 = ((vt1.float().cpu()[:, :, :T] - want_v).norm() / want_v.norm()).item()
+  print(f"merged q|k|V^T R={R} T={T} C={C}: rel {r1:.3e} / {r2:.3e}")
+  assert r1 < 6e-3 and r2 < 6e-3
+
+
 def test_plan_entry_that_cannot_run_falls_back(dev, tmp_path):
   """ADVICE r3 (medium) / VERDICT r3 item 8: a table entry naming the persistent tile 13 for a convolution key
   whose epilogue (bias + addend + residual together) is not instantiated there, reached through BOTH launch
