@@ -35,7 +35,7 @@ def main():
   kn, ks, ke = key("Kernel_Name", "Name"), key("Start_Timestamp", "Start"), key("End_Timestamp", "End")
   kq = key("Queue_Id", "Queue", "Stream_Id")
   rows.sort(key=lambda r: int(r[ks]))
-  marks = [i for i, r in enumerate(rows) if "time_embedding_kernel" in r[kn]]
+  marks = [i for i, r in enumerate(rows) if "time_embedding_kernel" in r[kn] or "select_row_kernel" in r[kn]]
   if len(marks) < 2:
     sys.exit("fewer than two U-Net evaluations in the trace")
   k = args.eval if args.eval >= 0 else len(marks) // 2

@@ -35,7 +35,7 @@ for path in args:
   win = None
   for r in rows:
     n = r["Kernel_Name"]
-    if "time_embedding_kernel" in n:
+    if "time_embedding_kernel" in n or "select_row_kernel" in n:   # first launch of an evaluation (per-step MLP / row of the per-loop temb table)
       win = {"fam": collections.defaultdict(lambda: collections.defaultdict(float)),
              "dur": collections.defaultdict(float), "cnt": collections.defaultdict(int), "seen": set()}
     if win is None:

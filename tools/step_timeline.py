@@ -31,7 +31,7 @@ def main():
   gx = next((n for n in ("Grid_Size_X", "Grid_Size") if n in rows[0]), None)
   wx = next((n for n in ("Workgroup_Size_X", "Workgroup_Size") if n in rows[0]), None)
   rows.sort(key=lambda r: int(r[ks]))
-  marks = [i for i, r in enumerate(rows) if "time_embedding_kernel" in r[kn]]
+  marks = [i for i, r in enumerate(rows) if "time_embedding_kernel" in r[kn] or "select_row_kernel" in r[kn]]
   if len(marks) < 2:
     sys.exit("fewer than two U-Net evaluations in the trace")
   k = args.eval if args.eval >= 0 else len(marks) // 2

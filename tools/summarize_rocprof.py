@@ -26,7 +26,9 @@ def main():
   args = ap.parse_args()
   rows = list(csv.DictReader(open(args.stats_csv)))
   tot = sum(float(r["TotalDurationNs"]) for r in rows)
-  evals = sum(int(r["Calls"]) for r in rows if "time_embedding_kernel" in r["Name"])
+  # one cfg_ddim_kernel per U-Net evaluation (the step's first launch is select_row_kernel when the per-loop temb table
+  # is in use, time_embedding_kernel otherwise; the CFG + DDIM update ends every evaluation of bench.py)
+  evals = sum(int(r["Calls"]) for r in rows if "cfg_ddim_kernel" in r["Name"])
   gemm = [r for r in rows if "gemm_kernel<" in r["Name"] or "gemm3_kernel<" in r["Name"] or "st_tail_kernel<" in r["Name"]]
   # split-K reduces: the plain reduce launches and the GroupNorm launches that complete a deferred product
   red = [r for r in rows if "splitk_epilogue" in r["Name"] or ("gn_fused_kernel<" in r["Name"] and ", true>" in r["Name"])]
@@ -35,7 +37,7 @@ def main():
   gemm_calls = sum(int(r["Calls"]) for r in gemm)
   print("# rocprofv3 --kernel-trace --stats summary\n")
   print(f"* total kernel time: {tot / 1e6:.1f} ms over {sum(int(r['Calls']) for r in rows)} dispatches")
-  print(f"* U-Net evaluations in the run (time_embedding_kernel dispatches): {evals}")
+  print(f"* U-Net evaluations in the run (cfg_ddim_kernel dispatches): {evals}")
   if evals:
     print(f"* MFMA GEMM/conv family (`gemm_kernel<...>` / `gemm3_kernel<...>` / `st_tail_kernel<...>`, all tile shapes): {gemm_ns / 1e6:.1f} ms, "
           f"{gemm_calls} launches = **{gemm_ns / 1e6 / evals:.3f} ms per U-Net evaluation** "
