@@ -366,15 +366,22 @@ class UNet:
     self._conv_deferred(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
     return out
 
-  def _dup_rows(self, t, tag):
-    """[t; t] along dim 0 (a CFG pair leaving its common prefix on a path without ldm_st_block's in_rows)."""
-    n = t.shape[0]
-    full = self.buf.get(tag, (2 * n,) + tuple(t.shape[1:]), t.dtype)
-    ops.cast(t, full[:n])
-    ops.cast(t, full[n:])
+  def _pair_buf(self, tag, shape, dt, pair):
+    """(view, full): scratch for a tensor of `shape`; for a CFG pair the buffer has twice the rows and `view` is
+    its first half, so that leaving the common prefix is ONE copy of the first half onto the second (_dup_rows)."""
+    if not pair:
+      t = self.buf.get(tag, shape, dt)
+      return t, t
+    full = self.buf.get(tag + "_pair", (2 * shape[0],) + tuple(shape[1:]), dt)
+    return full[:shape[0]], full
+
+  def _dup_rows(self, full):
+    """full[n:] = full[:n] (a CFG pair leaving its common prefix on a path without ldm_st_block's in_rows)."""
+    n = full.shape[0] // 2
+    ops.cast(full[:n], full[n:])
     return full
 
-  def _st(self, st, x, out, pair=False):
+  def _st(self, st, x, out, pair=False, x_full=None):
     """`pair`: x holds the first half of out's rows and the second half is identical up to the first
     cross-attention (forward(paired_rows=True)); out and the context cover all rows."""
     B_, dt = self.buf, self.dtype
@@ -383,7 +390,7 @@ class UNet:
     scale = st.s ** -0.5
     t0 = B_.get("gn", (R, h, w, c), dt)
     self._gn(x, st.gn, GN_EPS_ST, False, t0)
-    ha = B_.get("st_a", (R, T, c), dt)
+    ha, ha_full = self._pair_buf("st_a", (R, T, c), dt, pair)
     ln = B_.get("st_ln", (R, T, c), dt)
     # each LayerNorm of the block normalises a row the preceding projection has just produced:
     # where the GEMM tile holds whole rows (C = 320) it is emitted by that GEMM's epilogue
@@ -417,7 +424,7 @@ class UNet:
     else:
       ops.linear(ln, st.qk1, qk)
       ops.bmm_nt(ln, st.v1, vt, transposed_out=True)
-    att = B_.get("st_att", (R, T, hs), dt)
+    att, att_full = self._pair_buf("st_att", (R, T, hs), dt, pair)
     ms = fold is not None and st.ms
     ops.attention(qk[..., :hs], qk[..., hs:], vt, att, st.heads, st.sp, scale, matrix_softmax=ms)
     ctx_k, ctx_vt = (st.ctx_k, st.ctx_vt) if self._rows is None else (st.ctx_k[self._rows], st.ctx_vt[self._rows])
@@ -429,7 +436,7 @@ class UNet:
     if pair and not (xtail and self._fused_block):
       # per-layer path: the pair leaves its common prefix here -- both halves get their copy of the self-attention's
       # output, the residual stream and the block input, and everything below covers all rows
-      att, ha, x = self._dup_rows(att, "st_att_pair"), self._dup_rows(ha, "st_a_pair"), self._dup_rows(x, "st_x_pair")
+      att, ha, x = self._dup_rows(att_full), self._dup_rows(ha_full), self._dup_rows(x_full)
       R = Ro
       ln = B_.get("st_ln", (R, T, c), dt)
       lnp = lambda i: (st.ln[i][0], st.ln[i][1], ln, LN_EPS) if fuse_ln else None
@@ -655,9 +662,9 @@ class UNet:
           half = R // 2
           self._flush()
           with ops.plan_scope(half, x.shape[1], dt):
-            tmp = B_.get("blk_r_pair", (half,) + tuple(dst.shape[1:3]) + (r.cout,), dt)
+            tmp, tmp_full = self._pair_buf("blk_r", (half,) + tuple(dst.shape[1:3]) + (r.cout,), dt, True)
             self._res(r, cur[:half], tall if tall.shape[0] == 1 else tall[:half], tmp)
-            self._st(st, tmp, dst, pair=True)
+            self._st(st, tmp, dst, pair=True, x_full=tmp_full)
         else:
           tmp = B_.get("blk_r", (R,) + tuple(dst.shape[1:3]) + (r.cout,), dt)
           self._res(r, cur, tall, tmp)
