@@ -266,6 +266,45 @@ def test_merged_qkv_launch_equals_the_two_launches(dev, R, T, C, H, S):
   assert r1 < 6e-3 and r2 < 6e-3
 
 
+@pytest.mark.parametrize("case", ["shift32", "shift64", "outliers"])
+@pytest.mark.parametrize("M,K,N", [(1024, 320, 768), (512, 1280, 1280)])
+def test_layernorm_fold_on_rows_with_a_large_mean(dev, case, M, K, N):
+  """the LayerNorm fold takes its row statistics in ONE pass (f32 sums of x and x^2, var = E[x^2] -
+  mean^2) and subtracts mean * colsum from the accumulated product; rows whose |mean| is far above their spread
+  are the hard case.  bf16 rows cannot carry more than 2^8 of mean / spread (the values' own rounding step), so
+  the cases are: a common offset of 32 and 64 sigma, and 1 % outlier channels at 60 sigma (what trained
+  checkpoints' residual streams show).  Gate: no worse than 1.5x the two-launch form (two-pass LayerNorm kernel ->
+  bf16 rows -> GEMM) on the same bf16 inputs, against the float64 oracle of those inputs."""
+  from ldm_tf2_amd import layout as L
+  BF = torch.bfloat16
+  g = torch.Generator().manual_seed(21)
+  x = torch.randn(M, K, generator=g)
+  if case == "outliers":
+    idx = torch.randperm(K, generator=g)[:max(1, K // 100)]
+    x[:, idx] += 60.0 * torch.sign(torch.randn(len(idx), generator=g))
+  else:
+    x = x + float(case[5:]) * torch.sign(torch.randn(M, 1, generator=g))
+  x = x.to(BF)
+  gamma, beta = 1.0 + 0.3 * torch.randn(K, generator=g), 0.2 * torch.randn(K, generator=g)
+  w = torch.randn(N, K, generator=g) * K ** -0.5
+  bias = torch.randn(N, generator=g)
+  xd = x.double()
+  mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+  ref = ((xd - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()) @ w.double().t() + bias.double()
+  wq, cs, bb = L.ln_fold(w, gamma.numpy(), beta.numpy(), bias.numpy(), BF, dev)
+  out = torch.full((M, N), float("nan"), dtype=BF, device=dev)
+  ops.linear(x.to(dev), wq, out, bias=bb, ln_fold=(cs, 1e-5))
+  ln = torch.empty(M, K, dtype=BF, device=dev)
+  ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), ln, 1e-5)
+  out2 = torch.empty(M, N, dtype=BF, device=dev)
+  ops.linear(ln, w.to(BF).to(dev), out2, bias=bias.to(dev))
+  rel = lambda a: ((a.double().cpu() - ref).norm() / ref.norm()).item()
+  r, r2 = rel(out), rel(out2)
+  print(f"LN fold, {case}, M={M} K={K} N={N}: rel {r:.3e} (LayerNorm kernel + GEMM: {r2:.3e})")
+  assert torch.isfinite(out.float()).all()
+  assert r <= max(4e-3, 1.5 * r2)
+
+
 def test_plan_entry_that_cannot_run_falls_back(dev, tmp_path):
   """ADVICE r3 (medium) / VERDICT r3 item 8: a table entry naming the persistent tile 13 for a convolution key
   whose epilogue (bias + addend + residual together) is not instantiated there, reached through BOTH launch
