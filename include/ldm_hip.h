@@ -159,6 +159,17 @@ typedef struct {
    * the GroupNormalization that follows, one launch).  Ignored when the plan does not split K
    * (ldm_gemm_splits tells: the product is then complete when ldm_gemm returns). */
   int32_t defer_reduce;
+  /* conv = 1, stride 1, no upsample: a SECOND A operand for the K columns beyond 9*Cin.  K = 9*Cin + Cin2 and
+   *     out = conv3x3(a) . W[:, :9*Cin]^T  +  a2 . W[:, 9*Cin:]^T  (+ bias ...),
+   * the extra columns being a 1x1 convolution over the NHWC image a2 [B][H][W][Cin2] (pixel stride lda2, dtype of
+   * a) read at the output pixel.  The ResidualBlock's shortcut (unet.py:379-380, :393-397: a Dense over the block
+   * input where the channel count changes, added to the second convolution's output) then accumulates inside that
+   * convolution's K loop: no launch and no [M][Cout] tensor of its own; pass bias = conv bias + shortcut bias.
+   * Cin2 a multiple of the K-tile (64 bf16 / 32 f32 elements); implicit-GEMM tiles 1-12 and 17-19 (not the
+   * persistent or halo-staged ones); split-K, deferred reduce and every epilogue as without it.  NULL = off. */
+  const void* a2;
+  int64_t lda2;
+  int32_t Cin2;
 } ldm_gemm_params;
 
 int ldm_gemm(const ldm_gemm_params* p, void* stream);

@@ -39,6 +39,7 @@ class GemmParams(C.Structure):
       ("ln_out", c_vp), ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ld_ln", c_i64), ("ln_eps", c_f32),
       ("out2", c_vp), ("ld2", c_i64), ("stride2", c_i64), ("n_split", c_i32), ("rows2", c_i32),
       ("ln_cs", c_vp), ("defer_reduce", c_i32),
+      ("a2", c_vp), ("lda2", c_i64), ("Cin2", c_i32),
   ]
 
 

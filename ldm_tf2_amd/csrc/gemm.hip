@@ -222,6 +222,7 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
     if ((c == 1 || c == 7) && esize == 2 && p->tile != c) continue;   // bf16: their ping-ponged twins 11 / 9 are ~20 % faster
     if (c == 6 && esize == 2 && p->tile != 6) continue;   // bf16: tile 10 (same 128x160 tile, 64x80 wave tiles) is 10-14 % faster
     if (kBf16Only[c] && esize != 2) continue;
+    if (p->a2 && (is_persistent(c) || is_halo_ring(c)) && p->tile != c) continue;   // second A operand: implicit-GEMM tiles only
     if (kTiles[c].bn % 160 == 0 && p->tile != c && (p->N % kTiles[c].bn != 0 || no160)) continue;   // 160/320-column tiles: N = 160*k layers
     if (p->out2 && p->n_split % kTiles[c].bn != 0) continue;                        // every tile on one side of n_split
     if (geglu && c > 2 && c != 5 && c != 11 && c != 12 && c != 14 && c != 19) continue;
@@ -250,7 +251,7 @@ void choose(const ldm_gemm_params* p, int esize, int* cfg_out, int* split_out) {
   if (p->tile > 0 && p->tile < kNumTiles) best_cfg = p->tile;
   // where the model picks the 256x160 ping-pong tile for a stride-1 convolution the halo-staged twin
   // (tile 15) measures 2-6 % faster from three channel chunks up (tools/conv_ring_probe.py)
-  else if (best_cfg == 9 && halo_ring_ok(p) && p->N % 160 == 0 && !p->out2 && !p->ln_out && ktiles / best_split >= 27)
+  else if (best_cfg == 9 && halo_ring_ok(p) && p->N % 160 == 0 && !p->out2 && !p->ln_out && !p->a2 && ktiles / best_split >= 27)
     best_cfg = 15;
   *cfg_out = best_cfg;
   *split_out = best_split;
@@ -302,6 +303,11 @@ void build_args(const ldm_gemm_params* p, int cfg, int split, int kps, GemmArgs*
   a.ln_out = (char*)p->ln_out; a.ln_gamma = p->ln_gamma; a.ln_beta = p->ln_beta; a.ld_ln = p->ld_ln;
   a.ln_eps = p->ln_eps;
   a.out2 = (char*)p->out2; a.ld2 = p->ld2; a.stride2 = p->stride2; a.n_split = p->n_split; a.rows2 = p->rows2;
+  a.kt9 = cdiv(p->K, bke);                          // no second operand: every K-tile belongs to the first
+  if (p->a2) {
+    a.a2 = (const char*)p->a2; a.lda2 = p->lda2; a.kt9 = 9 * p->Cin / bke;
+    a.a2_bytes = (uint32_t)((((int64_t)p->M - 1) * p->lda2 + p->Cin2) * esize);
+  }
   // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
   const int nout = p->act == LDM_ACT_GEGLU ? p->N / 2 : p->N;
   auto al = [](const void* q, int by) { return ((uintptr_t)q % by) == 0; };
@@ -386,7 +392,14 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   if (p->conv) {
     LDM_CHECK_ARG(p->Cin > 0 && p->Cin % bke == 0, "ldm_gemm(conv): Cin=%d must be a multiple of %d",
                   p->Cin, bke);
-    LDM_CHECK_ARG(p->K == 9 * p->Cin, "ldm_gemm(conv): K must be 9*Cin");
+    LDM_CHECK_ARG(p->K == 9 * p->Cin + (p->a2 ? p->Cin2 : 0), "ldm_gemm(conv): K must be 9*Cin (+ Cin2 with a second operand)");
+    if (p->a2) {
+      LDM_CHECK_ARG(p->stride == 1 && !p->upsample && !p->no_lead_pad && p->OH == p->H && p->OW == p->W && !p->a_scale,
+                    "ldm_gemm(conv): the second operand (a2) needs a stride-1, pad-1, non-upsampled convolution");
+      LDM_CHECK_ARG(p->Cin2 > 0 && p->Cin2 % bke == 0 && p->lda2 % epc == 0 && p->lda2 >= p->Cin2 && ((uintptr_t)p->a2 % 16) == 0,
+                    "ldm_gemm(conv): a2 needs Cin2 %% %d == 0, lda2 %% %d == 0 and 16-byte alignment", bke, epc);
+      LDM_CHECK_ARG((((int64_t)p->M - 1) * p->lda2 + p->Cin2) * esize < (1ll << 31), "ldm_gemm(conv): a2 extent must be < 2 GiB");
+    }
     LDM_CHECK_ARG(p->stride == 1 || p->stride == 2, "ldm_gemm(conv): stride must be 1 or 2");
     LDM_CHECK_ARG(p->B > 0 && p->H > 0 && p->W > 0 && p->OH > 0 && p->OW > 0, "ldm_gemm(conv): dims");
     LDM_CHECK_ARG(p->H < 32768 && p->W < 32768, "ldm_gemm(conv): H/W too large");
@@ -417,7 +430,8 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   // kernel of conv_halo.hip.  Without a prologue the implicit-GEMM kernel measures equal or
   // faster, so it stays the default.
   // (forced halo tiles are addressed as tile 21..23)
-  if (p->conv && p->stride == 1 && ((p->tile == 0 && p->a_scale) || p->tile > 20) && p->split_k <= 1) {
+  LDM_CHECK_ARG(!p->a2 || p->conv, "ldm_gemm: a2 (second A operand) is for conv = 1");
+  if (p->conv && p->stride == 1 && !p->a2 && ((p->tile == 0 && p->a_scale) || p->tile > 20) && p->split_k <= 1) {
     const int r = ldm_conv_halo_try(p, p->tile > 20 ? p->tile - 20 : 0, stream);
     if (r == 1) return LDM_OK;
     if (r < 0) return r;
@@ -446,6 +460,8 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   }
   if (p->act == LDM_ACT_GEGLU) LDM_CHECK_ARG(cfg <= 2 || cfg == 5 || cfg == 11 || cfg == 12 || cfg == 14 || cfg == 19, "ldm_gemm: GEGLU needs a tile whose width is a multiple of 64 (1, 2, 5, 11, 12)");
   LDM_CHECK_ARG(!kBf16Only[cfg] || esize == 2, "ldm_gemm: tile %d is bf16 only", cfg);
+  LDM_CHECK_ARG(!p->a2 || (!is_persistent(cfg) && !is_halo_ring(cfg) && cfg < kNumTiles),
+                "ldm_gemm: tile %d cannot take a second A operand (a2): implicit-GEMM tiles 1-12, 17-19 only", cfg);
   if (is_halo_ring(cfg))
     LDM_CHECK_ARG(halo_ring_ok(p) && p->N % kTiles[cfg].bn == 0 && !p->out2 && !p->ln_out,
                   "ldm_gemm: tile %d (halo-staged conv) needs a bf16 stride-1 3x3 convolution with W = 16 or 32, "

@@ -39,6 +39,16 @@ def conv_kernel(k_hwio, dtype, device):
   return _dev(k.permute(3, 0, 1, 2).reshape(cout, -1), dtype, device)
 
 
+def conv_shortcut_kernel(k_hwio, k_io, dtype, device):
+  """[Cout, 9*Cin + Cin2]: the 3x3 kernel's OHWI rows followed by the 1x1 shortcut's [out, in] rows -- ldm_gemm's
+  K order with a second A operand (conv3x3(..., x2=...): the ResBlock shortcut inside its second convolution)."""
+  k = torch.from_numpy(np.ascontiguousarray(k_hwio))
+  cout = k.shape[3]
+  sc = torch.from_numpy(np.ascontiguousarray(k_io)).t()
+  assert sc.shape[0] == cout
+  return _dev(torch.cat([k.permute(3, 0, 1, 2).reshape(cout, -1), sc], 1), dtype, device)
+
+
 def dense_kernel(k_io, dtype, device):
   return _dev(torch.from_numpy(np.ascontiguousarray(k_io)).t(), dtype, device)
 

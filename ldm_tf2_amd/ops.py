@@ -159,7 +159,7 @@ def _halo_ring_key(key, M, N, bn):
   """True if the problem `key` names can run on a halo-staged conv tile (gemm.hip halo_ring_ok)."""
   import re
   m = re.search(r"conv1 H(\d+) W(\d+) s1 u0 nlp0", key or "")
-  if not m:
+  if not m or " x2" in (key or ""):          # (a second A operand runs on the implicit-GEMM tiles only)
     return False
   H, W = int(m.group(1)), int(m.group(2))
   return W in (16, 32) and H % (256 // W) == 0 and M % 256 == 0 and N % bn == 0
@@ -168,6 +168,8 @@ def _halo_ring_key(key, M, N, bn):
 def plan_key(p) -> str:
   key = "M%d N%d K%d b%d conv%d H%d W%d s%d u%d nlp%d act%d dt%d odt%d" % (
       p.M, p.N, p.K, p.batch, p.conv, p.H, p.W, p.stride, p.upsample, p.no_lead_pad, p.act, p.dtype, p.out_dtype)
+  if p.a2:
+    key += " x2"            # second A operand (the ResBlock shortcut inside the convolution): K = 9 Cin + Cin2
   if p.out2 and p.n_split == 0:
     key += " t1"            # whole product stored transposed (linear_t)
   elif p.out2 and p.ln_cs:
@@ -283,7 +285,7 @@ def plan_candidates(M, N, K, batch, act, dtype, key=None):
       continue
     tiles = -(-M // bm) * -(-N // bn) * batch
     if tile in _PERSISTENT_TILES:
-      if N % bn == 0 and batch == 1 and tiles >= 128:
+      if N % bn == 0 and batch == 1 and tiles >= 128 and " x2" not in (key or ""):
         out.append((tile, 1))
       continue
     out.append((tile, 1))
@@ -498,13 +500,14 @@ def linear_t(x, wt, out_t, tile=0, bias=None, ln_fold=None):
 
 
 def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale, a_shift,
-                 a_silu, no_lead_pad=False):
+                 a_silu, no_lead_pad=False, x2=None):
   B, H, W, Cin = x.shape
   Cout = wt.shape[0]
   hs, ws_ = (2 * H, 2 * W) if upsample else (H, W)
   pads = 1 if no_lead_pad else 2
   OH, OW = (hs + pads - 3) // stride + 1, (ws_ + pads - 3) // stride + 1
-  assert wt.shape[1] == 9 * Cin and wt.is_contiguous() and wt.dtype == x.dtype
+  Cin2 = 0 if x2 is None else x2.shape[-1]
+  assert wt.shape[1] == 9 * Cin + Cin2 and wt.is_contiguous() and wt.dtype == x.dtype
   assert tuple(out.shape) == (B, OH, OW, Cout), (tuple(out.shape), (B, OH, OW, Cout))
   p = GemmParams()
   p.a, p.w, p.out = _ptr(x), _ptr(wt), _ptr(out)
@@ -515,7 +518,10 @@ def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, spl
     assert residual.dtype == out.dtype
     p.ldr = row_ld(residual)
   p.lda, p.ldc_m, p.ldc_n = row_ld(x), row_ld(out), 1
-  p.M, p.N, p.K, p.batch = B * OH * OW, Cout, 9 * Cin, 1
+  p.M, p.N, p.K, p.batch = B * OH * OW, Cout, 9 * Cin + Cin2, 1
+  if x2 is not None:
+    assert tuple(x2.shape[:3]) == (B, OH, OW) and x2.dtype == x.dtype and stride == 1 and not upsample
+    p.a2, p.lda2, p.Cin2 = _ptr(x2), row_ld(x2), Cin2
   if addend is not None:
     p.add_rows = OH * OW
     p.add_ld = addend.stride(0) if (addend.dim() == 2 and addend.shape[0] > 1) else 0
@@ -532,14 +538,16 @@ def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, spl
 
 
 def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residual=None,
-            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False, no_lead_pad=False, defer_reduce=False):
+            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False, no_lead_pad=False, defer_reduce=False, x2=None):
   """3x3 convolution, NHWC, pad 1 (Keras SAME for stride 1; the U-Net's explicit
   pad(1,1)+VALID for stride 2; `no_lead_pad`: the autoencoder's pad (0,1),(0,1)+VALID stride-2
   downsample, autoencoder.py:133), optional fused nearest-2x upsample of the input and optional
   GroupNorm(+SiLU) prologue on the input (a_scale/a_shift [B,Cin] from groupnorm_scale_shift).
-  x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout]."""
+  x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout].
+  `x2` [B,H,W,Cin2] (stride 1): out += x2 . wt[:, 9*Cin:]^T at the output pixel -- the ResBlock's 1x1 shortcut
+  (unet.py:393-397) inside this convolution's K loop; wt is then [Cout, 9*Cin + Cin2] (layout.conv_shortcut_kernel)."""
   p = _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale,
-                   a_shift, a_silu, no_lead_pad)
+                   a_shift, a_silu, no_lead_pad, x2)
   if defer_reduce and a_scale is None:
     # -> PendingReduce when the plan splits K (the caller owes `finish` or a consuming groupnorm), else None
     return _gemm_deferred(p, x.device, out, (x, wt, bias, addend, residual))

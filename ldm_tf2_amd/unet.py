@@ -22,6 +22,7 @@ changes results beyond float rounding order):
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import layout as L
@@ -44,9 +45,12 @@ class _Res:
     self.temb_k, self.temb_b = g("dense/kernel"), g("dense/bias")   # gathered by the U-Net
     self.gn2 = (L.vec(g("group_norm_2/gamma"), dev), L.vec(g("group_norm_2/beta"), dev))
     self.conv2 = (L.conv_kernel(g("conv2d_2/kernel"), dtype, dev), L.vec(g("conv2d_2/bias"), dev))
-    self.shortcut = None
+    self.shortcut = self.conv2_sc = None
     if (p + "/shortcut/kernel") in w:
       self.shortcut = (L.dense_kernel(g("shortcut/kernel"), dtype, dev), L.vec(g("shortcut/bias"), dev))
+      # the shortcut as extra K columns of the second convolution (ldm_gemm a2): [Cout, 9 Cout + Cin], bias sum
+      self.conv2_sc = (L.conv_shortcut_kernel(g("conv2d_2/kernel"), g("shortcut/kernel"), dtype, dev),
+                       L.vec(np.asarray(g("conv2d_2/bias"), dtype=np.float32) + np.asarray(g("shortcut/bias"), dtype=np.float32), dev))
     self.temb_off = 0
 
 
@@ -128,7 +132,8 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=16384):
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=16384,
+               merge_shortcut=True):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -166,6 +171,7 @@ class UNet:
     # its own scratch and split-K workspace -- ONE fork after the timestep MLP, ONE join before the caller's
     # next launch -- so one branch's latency-bound launches run beside the other's convolutions.  Each
     # branch runs the launch plans of ITS row count.
+    self._merge_shortcut = bool(merge_shortcut)   # ResBlock shortcut inside its second convolution's K loop (A/B: False)
     self._merge_qkv = bool(merge_qkv)             # LayerNorm-folded q | k | V^T as one launch (A/B: False = two)
     # ... where a panel's workgroups can be dealt to the two sides of the launch evenly: at M = 32768 (128 panels,
     # 2 workgroups each for 6 + 3 n-tiles) the one-sided workgroups would be 6 and 3 tiles long
@@ -355,7 +361,8 @@ class UNet:
     t0 = B_.get("gn", tuple(x.shape), dt)
     self._gn(x, r.gn1, GN_EPS_RES, True, t0)
     res = x
-    if r.shortcut is not None:            # before conv1: the slabs of conv1 must survive until GN2
+    merged = r.shortcut is not None and self._merge_shortcut
+    if r.shortcut is not None and not merged:   # before conv1: the slabs of conv1 must survive until GN2
       res = B_.get("sc", (R, h, w, r.cout), dt)
       ops.linear(x, r.shortcut[0], res, bias=r.shortcut[1])
     h1 = B_.get("h1", (R, h, w, r.cout), dt)
@@ -363,7 +370,12 @@ class UNet:
     t1 = B_.get("gn", (R, h, w, r.cout), dt)
     self._gn(h1, r.gn2, GN_EPS_RES, True, t1, store_x=False)      # h1 has no other reader (unet.py:388-390)
     # conv2's reduce is left to the next GroupNorm (the following block's first op) when that reads `out`
-    self._conv_deferred(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
+    if merged:
+      # unet.py:393-397: shortcut(x) + conv2(...) as ONE product -- the shortcut's channels are extra K columns of
+      # the convolution (ldm_gemm a2): no launch and no [M, Cout] tensor of its own
+      self._conv_deferred(t1, r.conv2_sc[0], out, bias=r.conv2_sc[1], x2=x)
+    else:
+      self._conv_deferred(t1, r.conv2[0], out, bias=r.conv2[1], residual=res)
     return out
 
   def _pair_buf(self, tag, shape, dt, pair):

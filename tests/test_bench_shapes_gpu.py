@@ -68,23 +68,34 @@ def test_every_packaged_plan_matches_the_oracle(dev, key, plan):
   torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
   if f["conv"]:
     H, W, s, up = f["H"], f["W"], f["s"], bool(f["u"])
-    Cin = K // 9
+    # " x2": the ResBlock's second convolution (Cin = Cout = N) with its 1x1 shortcut over Cin2 = K - 9 N more
+    # channels of a second image as extra K columns (ldm_gemm a2)
+    Cin, Cin2 = (N, K - 9 * N) if f.get("x") else (K // 9, 0)
     OH = (2 * H if up else H) // s
     B = M // (OH * OH)
     assert B * OH * OH == M and not f["nlp"]
     x = _rand((B, H, W, Cin), dtype, 1)
     k = _rand((3, 3, Cin, N), dtype, 2, (9 * Cin) ** -0.5)
     bias = _rand((N,), torch.float32, 3)
-    wt = k.permute(3, 0, 1, 2).reshape(N, 9 * Cin).contiguous().to(dev)
+    wt = k.permute(3, 0, 1, 2).reshape(N, 9 * Cin).contiguous()
+    x2 = ks = x2d = None
+    if Cin2:
+      x2 = _rand((B, H, W, Cin2), dtype, 4)
+      ks = _rand((Cin2, N), dtype, 5, Cin2 ** -0.5)
+      wt = torch.cat([wt, ks.t()], 1).contiguous()
+      x2d = x2.to(dev)
+    wt = wt.to(dev)
     xd, bd = x.to(dev), bias.to(dev)
     outs = {}
     for name, (t, sp) in (("plan", (tile, split)), ("auto", (0, 0))):
       out = torch.zeros(B, OH, OH, N, dtype=dtype, device=dev)
-      ops.conv3x3(xd, wt, out, bias=bd, stride=s, upsample=up, tile=t, split_k=sp)
+      ops.conv3x3(xd, wt, out, bias=bd, stride=s, upsample=up, tile=t, split_k=sp, x2=x2d)
       outs[name] = out
     rows = sorted({0, B // 2, B - 1})
     xs = x[rows].float()
     ref = O.conv2d(O.upsample_nearest2x(xs) if up else xs, k.float(), bias, stride=s)
+    if Cin2:
+      ref = ref + O.dense(x2[rows].float(), ks.float(), None)
     for name, out in outs.items():
       _close(out[rows], ref, dtype, f"{name} conv {key}")
     _close(outs["plan"], outs["auto"].cpu(), dtype, f"plan vs auto {key}")

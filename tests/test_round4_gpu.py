@@ -305,6 +305,74 @@ def test_layernorm_fold_on_rows_with_a_large_mean(dev, case, M, K, N):
   assert r <= max(4e-3, 1.5 * r2)
 
 
+@pytest.mark.parametrize("dtype", DT, ids=["f32", "bf16"])
+@pytest.mark.parametrize("B,H,Cin,Cin2,Cout,tile,split", [
+    (2, 16, 128, 192, 320, 0, 0),        # cost model
+    (3, 8, 256, 128, 640, 9, 2),         # ping-pong tile, split-K: the shortcut's K-tiles fall into the last slab
+    (2, 32, 64, 64, 320, 10, 1),
+    (1, 16, 320, 960, 320, 2, 3),        # an output block's shape: the shortcut is wider than the convolution
+    (5, 4, 128, 256, 1280, 18, 4),       # 4x4 level, deep-ring small tile
+])
+def test_conv3x3_with_the_shortcut_as_a_second_operand(dev, dtype, B, H, Cin, Cin2, Cout, tile, split):
+  """ldm_gemm a2: out = conv3x3(x) W[:, :9 Cin]^T + x2 W[:, 9 Cin:]^T + bias (+ residual ...) -- the ResidualBlock's
+  1x1 shortcut over the block input (unet.py:379-380, :393-397) accumulated inside its second convolution's K loop.
+  Against the oracle's conv2d + dense; plain, with a deferred split-K reduce completed by the GroupNorm that
+  follows (ldm_groupnorm_splitk), and against the two-launch form on the same operands."""
+  from ldm_tf2_amd import layout as L
+  if dtype == torch.float32 and tile in (9, 10):
+    pytest.skip("bf16-only tile")
+  g = torch.Generator().manual_seed(31)
+  x = torch.randn(B, H, H, Cin, generator=g).to(dtype)
+  x2 = torch.randn(B, H, H, Cin2, generator=g).to(dtype)
+  k = torch.randn(3, 3, Cin, Cout, generator=g) * (9 * Cin) ** -0.5
+  ks = torch.randn(Cin2, Cout, generator=g) * Cin2 ** -0.5
+  b1, b2 = torch.randn(Cout, generator=g), torch.randn(Cout, generator=g)
+  want = O.conv2d(x.float(), k, b1) + O.dense(x2.float(), ks, b2)
+  wt = L.conv_shortcut_kernel(k.numpy(), ks.numpy(), dtype, dev)
+  bias = (b1 + b2).to(dev)
+  xd, x2d = x.to(dev), x2.to(dev)
+  out = torch.full((B, H, H, Cout), float("nan"), dtype=dtype, device=dev)
+  ops.conv3x3(xd, wt, out, bias=bias, x2=x2d, tile=tile, split_k=split)
+  gate = 2e-5 if dtype == torch.float32 else 6e-3
+  r = ((out.float().cpu().double() - want.double()).norm() / want.double().norm()).item()
+  # two-launch form: shortcut GEMM, then the convolution with it as the residual
+  res = torch.empty_like(out)
+  ops.linear(x2d, L.dense_kernel(ks.numpy(), dtype, dev), res, bias=b2.to(dev))
+  out2 = torch.empty_like(out)
+  ops.conv3x3(xd, L.conv_kernel(k.numpy(), dtype, dev), out2, bias=b1.to(dev), residual=res)
+  r2 = ((out2.float().cpu().double() - want.double()).norm() / want.double().norm()).item()
+  print(f"conv + shortcut as one product [{dtype}] B={B} H={H} {Cin}+{Cin2}->{Cout} tile {tile} split {split}: rel {r:.3e} (two launches {r2:.3e})")
+  assert r < gate and r <= r2 * 1.2 + 1e-6          # (no rounding of the shortcut's output to the storage type)
+  # a channel slice of a wider buffer as the second operand (the U-Net's concat buffers)
+  wide = torch.randn(B, H, H, Cin2 + 64, generator=g).to(dtype).to(dev)
+  wide[..., 32:32 + Cin2] = x2d
+  out3 = torch.empty_like(out)
+  ops.conv3x3(xd, wt, out3, bias=bias, x2=wide[..., 32:32 + Cin2], tile=tile, split_k=split)
+  assert torch.equal(out3, out)
+  # deferred reduce + GroupNorm in one launch
+  gamma, beta = (1.0 + 0.3 * torch.randn(Cout, generator=g)).to(dev), (0.2 * torch.randn(Cout, generator=g)).to(dev)
+  y = torch.empty_like(out)
+  pend = ops.conv3x3(xd, wt, y, bias=bias, x2=x2d, tile=tile, split_k=split, defer_reduce=True)
+  gn = torch.empty_like(out)
+  ops.groupnorm(y, gamma, beta, gn, 1e-5, silu=True, pending=pend)
+  gn0 = torch.empty_like(out)
+  ops.groupnorm(out, gamma, beta, gn0, 1e-5, silu=True)
+  assert torch.equal(y, out) and torch.equal(gn, gn0)
+
+
+def test_conv3x3_second_operand_is_rejected_where_it_cannot_run(dev):
+  BF = torch.bfloat16
+  x = torch.zeros(1, 16, 16, 64, dtype=BF, device=dev)
+  x2 = torch.zeros(1, 16, 16, 64, dtype=BF, device=dev)
+  w = torch.zeros(320, 9 * 64 + 64, dtype=BF, device=dev)
+  out = torch.empty(1, 16, 16, 320, dtype=BF, device=dev)
+  for tile in (13, 15):                       # persistent / halo-staged tiles
+    with pytest.raises(RuntimeError, match="a2"):
+      ops.conv3x3(x, w, out, x2=x2, tile=tile)
+  with pytest.raises(AssertionError):
+    ops.conv3x3(x, w, torch.empty(1, 8, 8, 320, dtype=BF, device=dev), x2=x2, stride=2)
+
+
 def test_plan_entry_that_cannot_run_falls_back(dev, tmp_path):
   """ADVICE r3 (medium) / VERDICT r3 item 8: a table entry naming the persistent tile 13 for a convolution key
   whose epilogue (bias + addend + residual together) is not instantiated there, reached through BOTH launch
