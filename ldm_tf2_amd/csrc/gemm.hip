@@ -286,7 +286,7 @@ void build_args(const ldm_gemm_params* p, int cfg, int split, int kps, GemmArgs*
   const int bke = 128 / esize;
   int64_t a_bytes;
   if (p->conv) a_bytes = (((int64_t)p->B * p->H * p->W - 1) * p->lda + p->Cin) * esize;
-  else a_bytes = (((int64_t)p->M - 1) * p->lda + p->K) * esize;
+  else a_bytes = (((int64_t)p->M - 1) * p->lda + (p->K - (p->a2 ? p->Cin2 : 0))) * esize;
   const int64_t w_bytes = (int64_t)p->N * p->K * esize;
   GemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -305,7 +305,7 @@ void build_args(const ldm_gemm_params* p, int cfg, int split, int kps, GemmArgs*
   a.out2 = (char*)p->out2; a.ld2 = p->ld2; a.stride2 = p->stride2; a.n_split = p->n_split; a.rows2 = p->rows2;
   a.kt9 = cdiv(p->K, bke);                          // no second operand: every K-tile belongs to the first
   if (p->a2) {
-    a.a2 = (const char*)p->a2; a.lda2 = p->lda2; a.kt9 = 9 * p->Cin / bke;
+    a.a2 = (const char*)p->a2; a.lda2 = p->lda2; a.kt9 = (p->K - p->Cin2) / bke;
     a.a2_bytes = (uint32_t)((((int64_t)p->M - 1) * p->lda2 + p->Cin2) * esize);
   }
   // vectorised epilogue: row-major output whose every 8-column piece is 16-byte addressable
@@ -430,7 +430,14 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   // kernel of conv_halo.hip.  Without a prologue the implicit-GEMM kernel measures equal or
   // faster, so it stays the default.
   // (forced halo tiles are addressed as tile 21..23)
-  LDM_CHECK_ARG(!p->a2 || p->conv, "ldm_gemm: a2 (second A operand) is for conv = 1");
+  if (p->a2 && !p->conv) {
+    LDM_CHECK_ARG(p->batch == 1 && p->Cin2 > 0 && p->Cin2 < p->K && p->Cin2 % bke == 0 && (p->K - p->Cin2) % bke == 0 &&
+                      p->lda2 % epc == 0 && p->lda2 >= p->Cin2 && ((uintptr_t)p->a2 % 16) == 0 && !p->ln_cs && !p->ln_out && !p->out2,
+                  "ldm_gemm: a2 (second A operand for the last Cin2 columns of K) needs batch 1, whole K-tiles on both "
+                  "sides, lda2 %% %d == 0, 16-byte alignment and a plain epilogue", epc);
+    LDM_CHECK_ARG((((int64_t)p->M - 1) * p->lda2 + p->Cin2) * esize < (1ll << 31), "ldm_gemm: a2 extent must be < 2 GiB");
+    a_bytes = (((int64_t)p->M - 1) * p->lda + (p->K - p->Cin2)) * esize;
+  }
   if (p->conv && p->stride == 1 && !p->a2 && ((p->tile == 0 && p->a_scale) || p->tile > 20) && p->split_k <= 1) {
     const int r = ldm_conv_halo_try(p, p->tile > 20 ? p->tile - 20 : 0, stream);
     if (r == 1) return LDM_OK;

@@ -37,8 +37,8 @@ struct GemmArgs {
   char* out2;                // transposed second output for the columns >= n_split (q|k|v in one launch)
   int64_t ld2, stride2;
   int n_split, rows2;
-  const char* a2;            // MODE 1, stride 1: second A operand (1x1 over image a2 at the output pixel) for the
-  int64_t lda2;              // K-tiles kt >= kt9 (= 9 Cin / K-tile; = ktiles when there is none)
+  const char* a2;            // MODE 0 / 1 (stride 1): second A operand, plain rows (MODE 1: a 1x1 over image a2 at the
+  int64_t lda2;              // output pixel) for the K-tiles kt >= kt9 (= K-tiles of the first; = ktiles when none)
   uint32_t a2_bytes;
   int kt9;
 };
@@ -201,14 +201,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   //       upsample: a_base = byte offset of image b, a_aux = ((oy-1) << 16) | ((ox-1) & 0xffff)
   // gemm: a_base = byte offset of row m (+ chunk), or kOOB for rows >= M
   int a_base[LA], a_mask[LA], a_aux[LA];
-  [[maybe_unused]] int a2_base[LA];                 // MODE 1: byte offset of output pixel m in the second operand
+  [[maybe_unused]] int a2_base[LA];                 // MODE 0 / 1: byte offset of row / output pixel m in the second operand
 #pragma unroll
   for (int i = 0; i < LA; ++i) {
     const int row = (i * NW + wave) * 8 + (lane >> 3);
     const int ck = (lane & 7) ^ ((row >> 1) & 7);
     const int m = m0 + row;
     a_base[i] = MODE == 0 ? (int)kOOB : 0; a_mask[i] = 0; a_aux[i] = 0;
-    if constexpr (MODE == 1) a2_base[i] = m < p.M ? (int)((int64_t)m * p.lda2 * ES) + ck * 16 : (int)kOOB;
+    if constexpr (MODE <= 1) a2_base[i] = m < p.M ? (int)((int64_t)m * p.lda2 * ES) + ck * 16 : (int)kOOB;
     if (m < p.M) {
       if constexpr (MODE != 0) {
         const int ohw = p.OH * p.OW;
@@ -252,14 +252,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmArgs p) {
   // K-tile kt -> loads into `stage`.  K is a multiple of the K-tile (checked on the host),
   // so only rows (M/N tails, conv padding) are ever masked, never K.
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(MODE == 1 && p.a2 ? p.a2 : p.a), 0, MODE == 1 && p.a2 ? p.a2_bytes : 0u, 0x00020000);
+      const_cast<char*>(MODE <= 1 && p.a2 ? p.a2 : p.a), 0, MODE <= 1 && p.a2 ? p.a2_bytes : 0u, 0x00020000);
   auto issue_tile = [&](int kt, int stage) {
     char* dA = smem + stage * STAGE + wave * 1024;
     char* dB = dA + BM * 128;
     int kb;                                          // byte column of the weight matrix
-    if (MODE == 1 && kt >= p.kt9) {                  // (wave-uniform) the K-tiles of the second operand: plain rows
+    if (MODE <= 1 && kt >= p.kt9) {                  // (wave-uniform) the K-tiles of the second operand: plain rows
       const int kb2 = (kt - p.kt9) * 128;
-      kb = 9 * p.Cin * ES + kb2;
+      kb = kt * 128;                                 // (weights: [N][K of the first operand | K2], K-tile kt as ever)
 #pragma unroll
       for (int i = 0; i < LA; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA2, (lds_ptr)(dA + i * NW * 1024), 16,

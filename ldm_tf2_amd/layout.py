@@ -121,6 +121,21 @@ def ln_fold(wt_nk, gamma, beta, bias, dtype, device, row_scale=None, bias_extra=
   return wq.contiguous().to(device), cs.contiguous().to(device), bb.contiguous().to(device)
 
 
+def ff_proj_fold(ff_k_io, ff_bias, proj_k_io, proj_bias, dtype, device):
+  """The feed-forward's output Dense and the SpatialTransformer's proj_out as ONE product (unet.py:313, :338, :363-365):
+      out = x + Wp (h + W2 g + b2) + bp  =  x + (Wp W2) g + Wp h + (Wp b2 + bp)
+  -- two linear layers with only a residual between them.  Returns ([C, 4C + C] = (Wp W2 | Wp), rows = outputs, K
+  contiguous; folded bias [C]) for `ops.linear(g, w, out, bias=b, residual=x, x2=h)`.  The product Wp W2 is formed in
+  float64 from the float32 master weights and rounded once."""
+  w2 = torch.from_numpy(np.ascontiguousarray(ff_k_io)).to(torch.float64)       # [4C, C]  (in, out)
+  wp = torch.from_numpy(np.ascontiguousarray(proj_k_io)).to(torch.float64)     # [C, C]   (in, out)
+  b2 = torch.from_numpy(np.ascontiguousarray(ff_bias)).to(torch.float64)
+  bp = torch.from_numpy(np.ascontiguousarray(proj_bias)).to(torch.float64)
+  w = torch.cat([(w2 @ wp).t(), wp.t()], 1)                                     # [C, 4C + C]
+  b = b2 @ wp + bp
+  return _dev(w.to(torch.float32), dtype, device), _dev(b.to(torch.float32), torch.float32, device)
+
+
 def ffn_aux(cs, bias):
   """ldm_ffn_geglu's `aux`: per 128 rows of the folded GEGLU weights their column sums (128) then their
   folded bias (128), float32 [8C / 128, 256]."""

@@ -410,19 +410,22 @@ def linear_ln_supported(n_out, dtype):
 
 
 def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_rows=0,
-           alpha=1.0, tile=0, split_k=0, ln=None, out2=None, ln_fold=None):
+           alpha=1.0, tile=0, split_k=0, ln=None, out2=None, ln_fold=None, x2=None):
   """out[..., n] = act(alpha * x[..., :] . wt[n, :] + bias[n] + addend[group]) + residual.
   x [..., K]; wt [N, K] contiguous; out [..., N] (N/2 wide for GEGLU).
   `ln=(gamma, beta, ln_out, eps)`: also writes ln_out = LayerNorm(out) (same shape/dtype).
   `out2` [G, N2, T']: the weight rows beyond out's width are a second projection whose result is
   stored TRANSPOSED per group of T = M/G rows (q|k into `out`, v into the attention kernel's
   V^T [rows, heads*Sp, T] in one launch).
+  `x2` [..., K2]: out = x . wt[:, :K]^T + x2 . wt[:, K:]^T + ...: two products over the same rows as ONE launch.
   `ln_fold=(cs, eps)`: out = LayerNorm(x) . W^T + b with the normalisation folded into the product:
   `wt` holds gamma (.) W, `bias` holds b + W beta, cs[n] = sum_k wt[n, k] (layout.ln_fold); the kernel
   derives the row statistics itself (bf16, persistent tiles)."""
-  K = x.shape[-1]
+  K1 = x.shape[-1]
+  K2 = 0 if x2 is None else x2.shape[-1]
+  K = K1 + K2
   N = wt.shape[0]
-  M = x.numel() // K
+  M = x.numel() // K1
   assert wt.shape[1] == K and wt.is_contiguous() and wt.dtype == x.dtype
   p = GemmParams()
   p.a, p.w, p.out = _ptr(x), _ptr(wt), _ptr(out)
@@ -434,6 +437,9 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
     p.ldr = row_ld(residual)
   p.lda, p.ldc_m, p.ldc_n = row_ld(x), row_ld(out), 1
   p.M, p.N, p.K, p.batch = M, N, K, 1
+  if x2 is not None:     # the last K2 columns of K multiply rows of a second matrix (ldm_gemm a2)
+    assert x2.numel() // K2 == M and x2.dtype == x.dtype
+    p.a2, p.lda2, p.Cin2 = _ptr(x2), row_ld(x2), K2
   if addend is not None:
     p.add_rows = add_rows if add_rows > 0 else M
     p.add_ld = addend.stride(0) if (addend.dim() == 2 and addend.shape[0] > 1) else 0

@@ -81,6 +81,11 @@ class _ST:
     self.ff_out = (L.dense_kernel(g("block/ffn/dense/kernel"), dtype, dev), L.vec(g("block/ffn/dense/bias"), dev))
     self.ln = [(L.vec(g(f"block/layernorm{i}/gamma"), dev), L.vec(g(f"block/layernorm{i}/beta"), dev))
                for i in (1, 2, 3)]
+    # bf16: FF-out and proj_out as one product over (hidden | residual stream) (layout.ff_proj_fold; per-layer path)
+    self.ffp = None
+    if fold_ln:
+      self.ffp = L.ff_proj_fold(g("block/ffn/dense/kernel"), g("block/ffn/dense/bias"), g("dense2/kernel"),
+                                g("dense2/bias"), dtype, dev)
     # bf16: the three LayerNorms folded into the projections they feed (ldm_gemm ln_cs): (w', cs, b')
     self.fold = None
     # matrix-side softmax (ldm_attention_ms): 40-wide heads padded to 48, together with the fold (the
@@ -133,7 +138,7 @@ class UNet:
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
                defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=16384,
-               merge_shortcut=True):
+               merge_shortcut=True, merge_ffproj=True):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -171,6 +176,7 @@ class UNet:
     # its own scratch and split-K workspace -- ONE fork after the timestep MLP, ONE join before the caller's
     # next launch -- so one branch's latency-bound launches run beside the other's convolutions.  Each
     # branch runs the launch plans of ITS row count.
+    self._merge_ffproj = bool(merge_ffproj)       # FF-out + proj_out as one folded product on the per-layer path (bf16; A/B: False)
     self._merge_shortcut = bool(merge_shortcut)   # ResBlock shortcut inside its second convolution's K loop (A/B: False)
     self._merge_qkv = bool(merge_qkv)             # LayerNorm-folded q | k | V^T as one launch (A/B: False = two)
     # ... where a panel's workgroups can be dealt to the two sides of the launch evenly: at M = 32768 (128 panels,
@@ -496,6 +502,11 @@ class UNet:
       if not fuse_ln:
         ops.layernorm(ha, st.ln[2][0], st.ln[2][1], ln, LN_EPS)
       ops.linear(ln, st.geglu[0], ff, bias=st.geglu[1], act=ops.ACT_GEGLU)
+    if st.ffp is not None and self._merge_ffproj:
+      # y = h + FF-out(ff) and proj_out(y) + x are two linear layers with a residual between them: ONE product over
+      # (ff | h) with the folded weights (Wp W2 | Wp) -- no proj_out launch, no y tensor (unet.py:313, :363-365)
+      ops.linear(ff, st.ffp[0], out, bias=st.ffp[1], residual=x, x2=ha)
+      return out
     ops.linear(ff, st.ff_out[0], hb, bias=st.ff_out[1], residual=ha)
     ops.linear(hb, st.proj_out[0], out, bias=st.proj_out[1], residual=x)
     return out

@@ -373,6 +373,37 @@ def test_conv3x3_second_operand_is_rejected_where_it_cannot_run(dev):
     ops.conv3x3(x, w, torch.empty(1, 8, 8, 320, dtype=BF, device=dev), x2=x2, stride=2)
 
 
+@pytest.mark.parametrize("M,C,tile,split", [(2048, 640, 0, 0), (1024, 1280, 9, 2), (512, 1280, 1, 3), (300, 320, 11, 1)])
+def test_ffout_and_proj_out_as_one_folded_product(dev, M, C, tile, split):
+  """out = x + Wp (h + W2 g + b2) + bp as ONE launch over (g | h) with the folded weights (Wp W2 | Wp)
+  (layout.ff_proj_fold; ldm_gemm a2 on plain rows; unet.py:313, :338, :363-365): against the float64 oracle of the
+  two Dense layers on the same bf16 inputs, and no worse than the two launches it replaces (whose intermediate y is
+  rounded to bf16)."""
+  from ldm_tf2_amd import layout as L
+  BF = torch.bfloat16
+  g = torch.Generator().manual_seed(41)
+  gg = torch.randn(M, 4 * C, generator=g).to(BF)
+  h = torch.randn(M, C, generator=g).to(BF)
+  x = torch.randn(M, C, generator=g).to(BF)
+  k2 = (torch.randn(4 * C, C, generator=g) * (4 * C) ** -0.5).numpy()
+  kp = (torch.randn(C, C, generator=g) * C ** -0.5).numpy()
+  b2, bp = torch.randn(C, generator=g).numpy(), torch.randn(C, generator=g).numpy()
+  y = h.double() + gg.double() @ torch.from_numpy(k2).double() + torch.from_numpy(b2).double()
+  want = x.double() + y @ torch.from_numpy(kp).double() + torch.from_numpy(bp).double()
+  w, b = L.ff_proj_fold(k2, b2, kp, bp, BF, dev)
+  assert tuple(w.shape) == (C, 5 * C)
+  out = torch.full((M, C), float("nan"), dtype=BF, device=dev)
+  ops.linear(gg.to(dev), w, out, bias=b, residual=x.to(dev), x2=h.to(dev), tile=tile, split_k=split)
+  yd = torch.empty(M, C, dtype=BF, device=dev)
+  ops.linear(gg.to(dev), L.dense_kernel(k2, BF, dev), yd, bias=torch.from_numpy(b2).to(dev), residual=h.to(dev))
+  out2 = torch.empty(M, C, dtype=BF, device=dev)
+  ops.linear(yd, L.dense_kernel(kp, BF, dev), out2, bias=torch.from_numpy(bp).to(dev), residual=x.to(dev))
+  rel = lambda a: ((a.double().cpu() - want).norm() / want.norm()).item()
+  r, r2 = rel(out), rel(out2)
+  print(f"FF-out + proj_out folded M={M} C={C} tile {tile} split {split}: rel {r:.3e} (two launches {r2:.3e})")
+  assert torch.isfinite(out.float()).all() and r < 5e-3 and r <= r2 * 1.2
+
+
 def test_plan_entry_that_cannot_run_falls_back(dev, tmp_path):
   """ADVICE r3 (medium) / VERDICT r3 item 8: a table entry naming the persistent tile 13 for a convolution key
   whose epilogue (bias + addend + residual together) is not instantiated there, reached through BOTH launch
