@@ -132,11 +132,14 @@ template <int N> __device__ __forceinline__ void wait_vm() {      // s_waitcnt v
 
 // NW: waves per workgroup, (NW / 2) x 2 over the 128 x 128 period tile: 8 (wave tile 32 x 64, 2 waves per SIMD) or
 // 4 (wave tile 64 x 64, one wave per SIMD with the whole 512-register file: 1/3 less LDS read traffic per MFMA)
-template <int C, int KT0, int KIND, int NW>
+// BM: rows of a panel, 128 or 64.  The 64-row form keeps the LDS image of the 128-row one (tiles of 128 rows, the
+// upper half unused) and halves the wave tile (16 x 64): half the MFMA work per barrier period at the same
+// skeleton, for launches whose 128-row panels would leave half the chip idle (M = 16384: 128 panels on 256 CUs).
+template <int C, int KT0, int KIND, int NW, int BM = 128>
 __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr bool PRE = KT0 > 0, POST = KIND != 0, XATT = KIND >= 3, FRONT = KIND == 4;
-  constexpr int BM = 128;
+  static_assert(BM == 128 || (BM == 64 && NW == 8), "panel height");
   constexpr int TM = BM / (NW / 2) / 16, RW = 16 * TM;   // 16-row blocks / rows of a wave tile
   constexpr int NH = 16 / NW;                            // LDS-DMA instructions per staged tile and wave
   static_assert(NW == 8 || NW == 4, "waves");          // (NW = 4 is not instantiated: see the file comment)
@@ -192,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
       const int m = m0 + srow[h];
-      xo[h] = m < p.M ? (uint32_t)((int64_t)(m >= p.in_rows ? m - p.in_rows : m) * p.ldx * 2) + sck[h] : kOOBf;
+      xo[h] = (m < p.M && srow[h] < BM) ? (uint32_t)((int64_t)(m >= p.in_rows ? m - p.in_rows : m) * p.ldx * 2) + sck[h] : kOOBf;
     }
 #pragma unroll
     for (int kt = 0; kt < KTP; ++kt)
@@ -326,6 +329,33 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
   auto ln_stats = [&]() {
     typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     const bf2 one = __builtin_bit_cast(bf2, 0x3f803f80u);
+    if constexpr (RW == 16) {
+      // 16 rows per wave: lane l takes row l & 15 and the 16-byte chunks c = (l >> 4) mod 4 of every K-tile; the four
+      // lanes of a row add up by two xor-shuffles, so every lane ends with ITS row's statistics (row lr = l & 15)
+      const int row = RW * wm + lr;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT1; ++kt) {
+        const char* base = smem + kt * TILE + row * 128;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const u32x4 cc = *(const u32x4*)(base + (((2 * lh + j + (row >> 1)) & 7) << 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t w = cc[e];
+            const bf2 a = __builtin_bit_cast(bf2, w);
+            s1 = __builtin_amdgcn_fdot2_f32_bf16(a, one, s1, false);
+            s2 = __builtin_amdgcn_fdot2_f32_bf16(a, a, s2, false);
+          }
+        }
+      }
+      s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+      s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+      const float ik = 1.0f / (float)C;
+      const float mu = s1 * ik;
+      rs_i[0] = rsqrtf(fmaxf(s2 * ik - mu * mu, 0.f) + p.eps);
+      nm_i[0] = -rs_i[0] * mu;
+    } else {
     const int half = lane >> 5;                                // lanes l and l + 32 split the row's chunks
     float ln_mu[RW / 32], ln_rs[RW / 32];
 #pragma unroll
@@ -359,6 +389,7 @@ __global__ __launch_bounds__(64 * NW) void st_tail_kernel(FfnArgs p) {
       const float mu = __shfl(ln_mu[i >> 1], 16 * (i & 1) + lr, 64);
       rs_i[i] = __shfl(ln_rs[i >> 1], 16 * (i & 1) + lr, 64);
       nm_i[i] = -rs_i[i] * mu;
+    }
     }
   };
 
@@ -935,7 +966,13 @@ extern "C" int ldm_st_block(const void* att, int64_t lda, int K0, const void* wo
   a.wo = (const char*)wo2; a.bo = bo2; a.wo_bytes = (uint32_t)(C * K0 * 2);
   a.wp = (const char*)wp; a.bp = bp; a.r1 = (const char*)r1; a.ldr1 = ldr1; a.wp_bytes = (uint32_t)(C * C * 2);
   a.ctx_k = (const char*)ctx_k; a.ctx_vt = (const char*)ctx_vt; a.Tk = Tk; a.ldv = ldv; a.T = T;
-  dim3 grid((M + 127) / 128);
-  hipLaunchKernelGGL((st_tail_kernel<320, 6, 4, kNW>), grid, dim3(64 * kNW), 0, (hipStream_t)stream, a);
+  // 128-row panels from 192 of them on (3/4 of the CUs busy); below that 64-row panels: twice the workgroups
+  if ((M + 127) / 128 >= 192) {
+    dim3 grid((M + 127) / 128);
+    hipLaunchKernelGGL((st_tail_kernel<320, 6, 4, kNW, 128>), grid, dim3(64 * kNW), 0, (hipStream_t)stream, a);
+  } else {
+    dim3 grid((M + 63) / 64);
+    hipLaunchKernelGGL((st_tail_kernel<320, 6, 4, kNW, 64>), grid, dim3(64 * kNW), 0, (hipStream_t)stream, a);
+  }
   return ldm_launch_status("ldm_st_block");
 }

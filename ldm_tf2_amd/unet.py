@@ -138,7 +138,7 @@ class UNet:
                context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
                defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=16384,
-               merge_shortcut=True, merge_ffproj=True):
+               merge_shortcut=True, merge_ffproj=True, block_min_rows=12288):
     # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
     # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
     # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
@@ -168,6 +168,7 @@ class UNet:
     self._fused_tail = bool(fused_tail)           # ... with the o-projection before and proj_out after it (ldm_st_tail)
     self._fused_block = bool(fused_block)         # ... and o1-projection + query projection in front (ldm_st_block)
     self._fused_xattn = bool(fused_xattn)         # ... and the cross-attention in front of the tail (ldm_st_xtail)
+    self._block_min_rows = int(block_min_rows)    # ... ldm_st_block alone from 192 panels of 64 rows on
     self._ffn_min_rows = int(ffn_min_rows)        # ... from 192 panels of 128 rows on (3/4 of the CUs busy)
     self._gn_single = bool(gn_single_launch)      # False: partial-sums + apply launches everywhere (A/B)
     self._defer_reduce = bool(defer_reduce)   # split-K reduces fused into the consuming GroupNorm (A/B: False)
@@ -451,7 +452,12 @@ class UNet:
     panel = (fold is not None and st.ffn_aux is not None and self._fused_ffn and Ro * T >= self._ffn_min_rows)
     xtail = (panel and self._fused_tail and self._fused_xattn and ms and hs == 384 and T % 128 == 0
              and ctx_k.shape[1] <= 80 and ctx_vt.shape[2] >= 80)
-    if pair and not (xtail and self._fused_block):
+    # ldm_st_block has a 64-row panel form for launches below 192 panels of 128 rows (round 4): it pays from 192
+    # panels of 64 rows on (`block_min_rows`), where the other row-panel launches (128-row panels only) do not
+    blk = (self._fused_block and fold is not None and st.ffn_aux is not None and self._fused_ffn and self._fused_tail
+           and self._fused_xattn and ms and hs == 384 and T % 128 == 0 and ctx_k.shape[1] <= 80 and ctx_vt.shape[2] >= 80
+           and Ro * T >= min(self._ffn_min_rows, self._block_min_rows))
+    if pair and not blk:
       # per-layer path: the pair leaves its common prefix here -- both halves get their copy of the self-attention's
       # output, the residual stream and the block input, and everything below covers all rows
       att, ha, x = self._dup_rows(att_full), self._dup_rows(ha_full), self._dup_rows(x_full)
@@ -460,7 +466,7 @@ class UNet:
       lnp = lambda i: (st.ln[i][0], st.ln[i][1], ln, LN_EPS) if fuse_ln else None
     hb = B_.get("st_b", (R, T, c), dt)
     q = B_.get("st_q", (R, T, hs), dt)
-    if xtail and self._fused_block:
+    if blk:
       # everything from the self-attention's output to the block's output: ONE row-panel launch (ldm_st_block)
       ops.st_block(att, st.o1[0], st.o1[1], ha, fold["q2"][0], fold["q2"][1], fold["q2"][2], ctx_k, ctx_vt,
                    st.o2[0], st.o2[1], fold["geglu"][0], st.ffn_aux, st.ff_out[0], st.ff_out[1], st.proj_out[0],
