@@ -196,8 +196,6 @@ def main():
                   help="skip the extra pass with the text encoder / decoder in the other precision")
   ap.add_argument("--no-plans", action="store_true",
                   help="A/B: ldm_gemm's cost-model tile/split choice only (ignore the packaged in-situ plan table)")
-  ap.add_argument("--fuse-gn", action="store_true",
-                  help="A/B: GroupNorm+SiLU as the halo conv's prologue instead of a separate pass")
   ap.add_argument("--tiny", action="store_true",
                   help="TEST ONLY (tests/test_multirank_gpu.py): a few-MB model of the same architecture so the "
                        "multi-rank path of this script runs in seconds; the JSON line says so and is not a benchmark")
@@ -249,7 +247,7 @@ def main():
                                      scope="autoencoder"),
   }
   log(rank, f"weights generated in {time.perf_counter() - t_build:.1f}s")
-  unet = UNet(**cfg["unet"], weights=w["unet"], dtype=dtype, device=dev, fuse_groupnorm=args.fuse_gn)
+  unet = UNet(**cfg["unet"], weights=w["unet"], dtype=dtype, device=dev)
   txt = TransformerModel(**cfg["cond_stage_model"], weights=w["cond_stage_model"], dtype=dec_dtype, device=dev)
   ae = AutoencoderKL(**cfg["autoencoder_kl"], weights=w["autoencoder"], dtype=dec_dtype, device=dev)
   ldm = dict(cfg["ldm"], num_ddim_steps=args.ddim_steps)

@@ -109,16 +109,8 @@ typedef struct {
   int32_t dtype;         /* of a, w */
   int32_t out_dtype;     /* of out, residual */
   int32_t split_k;       /* 0 = let the library choose */
-  int32_t tile;          /* 0 = auto; 1-19 force an implicit-GEMM tile (9-12: bf16 16x16x32 MFMA path, 13-14: persistent ping-pong kernel; there split_k < 0 sets the workgroups per row panel, 15-16: tiles 9 / 11 with the halo-staged A operand for stride-1 convolutions whose 256-row M-tile is whole lines of one image, W = 16 or 32, 17-19: the 64x64 / 128x64 / 128x128 tiles with a 4- / 3- / 3-stage LDS ring for launches of 1-3 workgroups per CU), 21-23 the round-1 halo-conv kernel */
+  int32_t tile;          /* 0 = auto; 1-19 force an implicit-GEMM tile (9-12: bf16 16x16x32 MFMA path, 13-14: persistent ping-pong kernel; there split_k < 0 sets the workgroups per row panel, 15-16: tiles 9 / 11 with the halo-staged A operand for stride-1 convolutions whose 256-row M-tile is whole lines of one image, W = 16 or 32, 17-19: the 64x64 / 128x64 / 128x128 tiles with a 4- / 3- / 3-stage LDS ring for launches of 1-3 workgroups per CU), */
   float alpha;
-  /* conv prologue (stride-1 halo path only): A := [silu](A*a_scale[b][ci] + a_shift[b][ci]) on
-   * in-image pixels, applied ONCE per element in LDS before the zero padding -- the
-   * GroupNormalization affine (+ tf.nn.silu) that precedes every ResBlock conv
-   * (unet.py:383,390; autoencoder.py:43-51) with scale = rstd*gamma, shift = beta - mean*scale
-   * from ldm_groupnorm_finalize.  float32 [B][Cin]; NULL = no prologue. */
-  const float* a_scale;
-  const float* a_shift;
-  int32_t a_silu;
   /* conv: 0 = one zero row/column before the image (Keras SAME at stride 1; pad (1,1)+VALID at
    * stride 2, unet.py:26-27); 1 = none before, one after -- the autoencoder's
    * pad [[0,1],[0,1]] + stride-2 VALID downsample (autoencoder.py:133-136); stride 2 only. */
@@ -235,16 +227,6 @@ int ldm_groupnorm_fused_supported(int B, int HW, int C, int groups, int dtype);
 int ldm_groupnorm_fused(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out,
                         int64_t ldo, int B, int HW, int C, int groups, float eps, int silu, int dtype,
                         void* stream);
-/* Instead of ldm_groupnorm_apply: fold the statistics into per-(sample, channel)
- * scale = rstd*gamma and shift = beta - mean*scale (float32 [B][C]) for a consumer that
- * normalises on the fly (ldm_gemm's a_scale / a_shift conv prologue). */
-int ldm_groupnorm_finalize(const float* partial, const float* gamma, const float* beta, float* scale,
-                           float* shift, int B, int HW, int C, int groups, int nchunks, float eps,
-                           void* stream);
-/* 1 if ldm_gemm would run these conv params on the halo path (and so accepts a_scale/a_shift),
- * else 0.  Pure host-side query: no launch. */
-int ldm_conv_prologue_supported(const ldm_gemm_params* p);
-
 /* LayerNormalization over the last axis (unet.py:304-306; transformer.py:165,170,209). */
 int ldm_layernorm(const void* x, int64_t ldx, const float* gamma, const float* beta, void* out,
                   int64_t ldo, int rows, int C, float eps, int dtype, void* stream);

@@ -35,7 +35,7 @@ class GemmParams(C.Structure):
       ("OH", c_i32), ("OW", c_i32), ("stride", c_i32), ("upsample", c_i32),
       ("act", c_i32), ("dtype", c_i32), ("out_dtype", c_i32), ("split_k", c_i32),
       ("tile", c_i32), ("alpha", c_f32),
-      ("a_scale", c_vp), ("a_shift", c_vp), ("a_silu", c_i32), ("no_lead_pad", c_i32),
+      ("no_lead_pad", c_i32),
       ("ln_out", c_vp), ("ln_gamma", c_vp), ("ln_beta", c_vp), ("ld_ln", c_i64), ("ln_eps", c_f32),
       ("out2", c_vp), ("ld2", c_i64), ("stride2", c_i64), ("n_split", c_i32), ("rows2", c_i32),
       ("ln_cs", c_vp), ("defer_reduce", c_i32),
@@ -61,9 +61,6 @@ SIGNATURES = {
                                       c_i32, c_vp]),
     "ldm_groupnorm_apply": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32,
                                     c_i32, c_i32, c_i32, c_f32, c_i32, c_i32, c_vp]),
-    "ldm_groupnorm_finalize": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32,
-                                       c_f32, c_vp]),
-    "ldm_conv_prologue_supported": (c_i32, [C.POINTER(GemmParams)]),
     "ldm_layernorm": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_f32,
                               c_i32, c_vp]),
     "ldm_softmax_rows": (c_i32, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_f32,

@@ -17,8 +17,6 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 // ---- error plumbing --------------------------------------------------------
 void ldm_set_error(const char* fmt, ...);
-// conv_halo.hip: 1 = launched by a halo kernel, 0 = not eligible (use implicit GEMM), < 0 error
-int ldm_conv_halo_try(const ldm_gemm_params* p, int cfg, void* stream);
 #define LDM_CHECK_ARG(cond, ...)     \
   do {                               \
     if (!(cond)) {                   \

@@ -394,7 +394,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
                   p->Cin, bke);
     LDM_CHECK_ARG(p->K == 9 * p->Cin + (p->a2 ? p->Cin2 : 0), "ldm_gemm(conv): K must be 9*Cin (+ Cin2 with a second operand)");
     if (p->a2) {
-      LDM_CHECK_ARG(p->stride == 1 && !p->upsample && !p->no_lead_pad && p->OH == p->H && p->OW == p->W && !p->a_scale,
+      LDM_CHECK_ARG(p->stride == 1 && !p->upsample && !p->no_lead_pad && p->OH == p->H && p->OW == p->W,
                     "ldm_gemm(conv): the second operand (a2) needs a stride-1, pad-1, non-upsampled convolution");
       LDM_CHECK_ARG(p->Cin2 > 0 && p->Cin2 % bke == 0 && p->lda2 % epc == 0 && p->lda2 >= p->Cin2 && ((uintptr_t)p->a2 % 16) == 0,
                     "ldm_gemm(conv): a2 needs Cin2 %% %d == 0, lda2 %% %d == 0 and 16-byte alignment", bke, epc);
@@ -405,7 +405,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     LDM_CHECK_ARG(p->H < 32768 && p->W < 32768, "ldm_gemm(conv): H/W too large");
     LDM_CHECK_ARG(!(p->upsample && p->stride != 1), "ldm_gemm(conv): upsample needs stride 1");
     const int hs = p->upsample ? 2 * p->H : p->H, wsz = p->upsample ? 2 * p->W : p->W;
-    LDM_CHECK_ARG(!p->no_lead_pad || (p->stride == 2 && !p->a_scale), "ldm_gemm(conv): no_lead_pad needs stride 2");
+    LDM_CHECK_ARG(!p->no_lead_pad || p->stride == 2, "ldm_gemm(conv): no_lead_pad needs stride 2");
     const int padsum = p->no_lead_pad ? 1 : 2;
     LDM_CHECK_ARG(p->OH == (hs + padsum - 3) / p->stride + 1 && p->OW == (wsz + padsum - 3) / p->stride + 1,
                   "ldm_gemm(conv): OH/OW inconsistent with H/W/stride/upsample");
@@ -426,10 +426,6 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
   }
   LDM_CHECK_ARG(p->ldc_n == 1 || p->ldc_m == 1, "ldm_gemm: one of ldc_m / ldc_n must be 1");
 
-  // stride-1 convolutions with a GroupNorm prologue (or a forced halo tile): halo-staged
-  // kernel of conv_halo.hip.  Without a prologue the implicit-GEMM kernel measures equal or
-  // faster, so it stays the default.
-  // (forced halo tiles are addressed as tile 21..23)
   if (p->a2 && !p->conv) {
     LDM_CHECK_ARG(p->batch == 1 && p->Cin2 > 0 && p->Cin2 < p->K && p->Cin2 % bke == 0 && (p->K - p->Cin2) % bke == 0 &&
                       p->lda2 % epc == 0 && p->lda2 >= p->Cin2 && ((uintptr_t)p->a2 % 16) == 0 && !p->ln_cs && !p->ln_out && !p->out2,
@@ -438,16 +434,10 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     LDM_CHECK_ARG((((int64_t)p->M - 1) * p->lda2 + p->Cin2) * esize < (1ll << 31), "ldm_gemm: a2 extent must be < 2 GiB");
     a_bytes = (((int64_t)p->M - 1) * p->lda + (p->K - p->Cin2)) * esize;
   }
-  if (p->conv && p->stride == 1 && !p->a2 && ((p->tile == 0 && p->a_scale) || p->tile > 20) && p->split_k <= 1) {
-    const int r = ldm_conv_halo_try(p, p->tile > 20 ? p->tile - 20 : 0, stream);
-    if (r == 1) return LDM_OK;
-    if (r < 0) return r;
-  }
   LDM_CHECK_ARG(!p->ln_cs || (p->dtype == LDM_BF16 && p->out_dtype == LDM_BF16 && !p->conv && p->batch == 1 && !p->ln_out),
                 "ldm_gemm: ln_cs (LayerNorm fold) needs bf16 plain rows, batch 1 (persistent tiles 13 / 14)");
-  LDM_CHECK_ARG(!p->a_scale, "ldm_gemm: the a_scale/a_shift prologue needs the stride-1 halo conv path "
-                             "(shape not eligible: use ldm_groupnorm_apply + a plain conv)");
 
+  LDM_CHECK_ARG(p->tile >= 0 && p->tile < kNumTiles, "ldm_gemm: tile %d does not exist (0 = auto, 1-%d)", p->tile, kNumTiles - 1);
   int cfg, split, kps;
   final_plan(p, &cfg, &split, &kps);
   if (p->ln_out) {

@@ -264,43 +264,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const TI* x, int64_t 
     Elem<TO>::st(o + c, __expf(Elem<TI>::ld(r + c) * scale - m) * inv);
 }
 
-// one block per sample: group statistics -> per-channel scale / shift
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta,
-                                                          float* __restrict__ scale,
-                                                          float* __restrict__ shift, int HW, int C, int G,
-                                                          int nchunks, float eps) {
-  __shared__ float s_mean[64], s_rstd[64];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int cpg = C / G;
-  for (int g0 = 0; g0 < G; g0 += 32) {
-    const int g = g0 + (tid >> 3), sub = tid & 7;
-    float t1 = 0.f, t2 = 0.f;
-    if (g < G)
-      for (int c = sub; c < nchunks; c += 8) {
-        const float* o = partial + (((int64_t)b * nchunks + c) * G + g) * 2;
-        t1 += o[0]; t2 += o[1];
-      }
-#pragma unroll
-    for (int o = 4; o > 0; o >>= 1) { t1 += __shfl_xor(t1, o, 64); t2 += __shfl_xor(t2, o, 64); }
-    if (g < G && sub == 0) {
-      const float n = (float)HW * (float)cpg;
-      const float mean = t1 / n;
-      float var = t2 / n - mean * mean;
-      var = var < 0.f ? 0.f : var;
-      s_mean[g] = mean;
-      s_rstd[g] = rsqrtf(var + eps);
-    }
-  }
-  __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    const int g = c / cpg;
-    const float sc = s_rstd[g] * gamma[c];
-    scale[(int64_t)b * C + c] = sc;
-    shift[(int64_t)b * C + c] = beta[c] - s_mean[g] * sc;
-  }
-}
 
 }  // namespace
 
@@ -333,17 +296,6 @@ extern "C" int ldm_groupnorm_fused(const void* x, int64_t ldx, const float* gamm
   else
     gn_fused_launch<float>(pl, grid, s, x, ldx, gamma, beta, out, ldo, B, HW, C, groups, eps, silu);
   return ldm_launch_status("ldm_groupnorm_fused");
-}
-
-extern "C" int ldm_groupnorm_finalize(const float* partial, const float* gamma, const float* beta,
-                                      float* scale, float* shift, int B, int HW, int C, int groups,
-                                      int nchunks, float eps, void* stream) {
-  LDM_CHECK_ARG(partial && gamma && beta && scale && shift, "ldm_groupnorm_finalize: null pointer");
-  LDM_CHECK_ARG(B > 0 && HW > 0 && C > 0 && groups > 0 && groups <= 64 && C % groups == 0 && nchunks > 0,
-                "ldm_groupnorm_finalize: bad dims");
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, partial, gamma, beta,
-                     scale, shift, HW, C, groups, nchunks, eps);
-  return ldm_launch_status("ldm_groupnorm_finalize");
 }
 
 extern "C" int ldm_groupnorm_nchunks(int B, int HW, int C) {

@@ -313,7 +313,7 @@ def resolve_plan(p: GemmParams):
   """Applies the active plan table to an auto-planned problem (tile == 0 and split_k == 0); True if
   the table supplied the plan."""
   active = _active()
-  if p.tile == 0 and p.split_k == 0 and not p.a_scale and not p.ln_out and (active or _PLAN_RECORD is not None):
+  if p.tile == 0 and p.split_k == 0 and not p.ln_out and (active or _PLAN_RECORD is not None):
     key = plan_key(p)
     if _PLAN_RECORD is not None:
       _PLAN_RECORD[key] = (p.M, p.N, p.K, p.batch, p.act, p.dtype)
@@ -505,8 +505,7 @@ def linear_t(x, wt, out_t, tile=0, bias=None, ln_fold=None):
   return out_t
 
 
-def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale, a_shift,
-                 a_silu, no_lead_pad=False, x2=None):
+def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, no_lead_pad=False, x2=None):
   B, H, W, Cin = x.shape
   Cout = wt.shape[0]
   hs, ws_ = (2 * H, 2 * W) if upsample else (H, W)
@@ -535,36 +534,23 @@ def _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, spl
   p.stride, p.upsample, p.no_lead_pad = stride, int(bool(upsample)), int(bool(no_lead_pad))
   p.act, p.dtype, p.out_dtype, p.alpha = ACT_NONE, code(x.dtype), code(out.dtype), 1.0
   p.tile, p.split_k = tile, split_k
-  if a_scale is not None:
-    assert tuple(a_scale.shape) == (B, Cin) and tuple(a_shift.shape) == (B, Cin)
-    assert a_scale.is_contiguous() and a_shift.is_contiguous()
-    p.a_scale, p.a_shift = _ptr(_f32(a_scale, "a_scale")), _ptr(_f32(a_shift, "a_shift"))
-    p.a_silu = int(bool(a_silu))
   return p
 
 
 def conv3x3(x, wt, out, bias=None, stride=1, upsample=False, addend=None, residual=None,
-            tile=0, split_k=0, a_scale=None, a_shift=None, a_silu=False, no_lead_pad=False, defer_reduce=False, x2=None):
+            tile=0, split_k=0, no_lead_pad=False, defer_reduce=False, x2=None):
   """3x3 convolution, NHWC, pad 1 (Keras SAME for stride 1; the U-Net's explicit
   pad(1,1)+VALID for stride 2; `no_lead_pad`: the autoencoder's pad (0,1),(0,1)+VALID stride-2
-  downsample, autoencoder.py:133), optional fused nearest-2x upsample of the input and optional
-  GroupNorm(+SiLU) prologue on the input (a_scale/a_shift [B,Cin] from groupnorm_scale_shift).
+  downsample, autoencoder.py:133), optional fused nearest-2x upsample of the input.
   x [B,H,W,Cin] (channel slice allowed); wt [Cout, 9*Cin] = OHWI; out [B,OH,OW,Cout].
   `x2` [B,H,W,Cin2] (stride 1): out += x2 . wt[:, 9*Cin:]^T at the output pixel -- the ResBlock's 1x1 shortcut
   (unet.py:393-397) inside this convolution's K loop; wt is then [Cout, 9*Cin + Cin2] (layout.conv_shortcut_kernel)."""
-  p = _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, a_scale,
-                   a_shift, a_silu, no_lead_pad, x2)
-  if defer_reduce and a_scale is None:
+  p = _conv_params(x, wt, out, bias, stride, upsample, addend, residual, tile, split_k, no_lead_pad, x2)
+  if defer_reduce:
     # -> PendingReduce when the plan splits K (the caller owes `finish` or a consuming groupnorm), else None
     return _gemm_deferred(p, x.device, out, (x, wt, bias, addend, residual))
   _gemm(p, x.device)
   return out
-
-
-def conv3x3_prologue_supported(x, wt, out, stride=1, upsample=False, tile=0):
-  """True if this convolution runs on the halo path, i.e. accepts the GroupNorm prologue."""
-  p = _conv_params(x, wt, out, None, stride, upsample, None, None, tile, 0, None, None, False)
-  return bool(lib.ldm_conv_prologue_supported(C.byref(p)))
 
 
 def bmm_nt(a, w, out, alpha=1.0, bias=None, transposed_out=False, tile=0):
@@ -646,24 +632,6 @@ def groupnorm(x, gamma, beta, out, eps, silu=False, groups=32, partial=None, fus
                                 nch, float(eps), int(bool(silu)), dt, _stream()),
         "ldm_groupnorm_apply")
   return out
-
-
-def groupnorm_scale_shift(x, gamma, beta, scale, shift, eps, groups=32, partial=None):
-  """GroupNorm statistics of x [B,H,W,C] folded into scale/shift [B,C] (float32) for a
-  consumer that normalises on the fly (conv3x3's a_scale / a_shift)."""
-  B, C = x.shape[0], x.shape[-1]
-  HW = x.numel() // (B * C)
-  nch = lib.ldm_groupnorm_nchunks(B, HW, C)
-  if partial is None:
-    partial = torch.empty(B * nch * groups * 2, dtype=torch.float32, device=x.device)
-  assert partial.numel() >= B * nch * groups * 2
-  assert tuple(scale.shape) == (B, C) and tuple(shift.shape) == (B, C)
-  check(lib.ldm_groupnorm_partial(_ptr(x), row_ld(x), _ptr(partial), B, HW, C, groups, nch,
-                                  code(x.dtype), _stream()), "ldm_groupnorm_partial")
-  check(lib.ldm_groupnorm_finalize(_ptr(partial), _ptr(_f32(gamma, "gamma")), _ptr(_f32(beta, "beta")),
-                                   _ptr(_f32(scale, "scale")), _ptr(_f32(shift, "shift")), B, HW, C,
-                                   groups, nch, float(eps), _stream()), "ldm_groupnorm_finalize")
-  return scale, shift
 
 
 def layernorm(x, gamma, beta, out, eps=1e-5):

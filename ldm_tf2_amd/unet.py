@@ -135,16 +135,10 @@ class UNet:
   def __init__(self, model_channels=320, out_channels=4, num_blocks=2,
                attention_resolutions=(4, 2, 1), dropout_rate=0.1, channel_mult=(1, 2, 4, 4),
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
-               context_dim=1280, init="keras", seed=2, fuse_groupnorm=False, fuse_layernorm=False, fuse_qkv=True,
+               context_dim=1280, init="keras", seed=2, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
                defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=16384,
                merge_shortcut=True, merge_ffproj=True, block_min_rows=12288):
-    # fuse_groupnorm: fold GroupNorm+SiLU into the halo-staged conv (conv_halo.hip) instead
-    # of a separate normalise pass.  Measured on MI355X at R=32 it LOSES (15.1 vs 12.5 ms per
-    # step): every n-tile of a conv re-normalises its halo (N/BN-fold redundant SiLU work on
-    # the VALU), which costs more than the one streaming pass it removes.  Kept as an
-    # option (parity-tested) for wider-N tiles in a later round.
-    self.fuse_groupnorm = fuse_groupnorm
     # fuse_layernorm: the transformer blocks' LayerNorms come out of the producing GEMM's epilogue
     # where its tile holds whole rows (C = 320).  Measured on MI355X at R=32: 11.02 vs 10.95 ms per
     # step -- the whole-row 128x320 tile (one workgroup per CU) plus the extra epilogue pass cost
@@ -191,7 +185,6 @@ class UNet:
     self._lane_state = {}
     self._rows = None                     # a lane's slice of the rows (context K / V^T); None = all rows
     self._pend = None
-    self._fuse_cache = {}
     self._model_channels = model_channels
     self._out_channels = out_channels
     self._num_blocks = num_blocks
@@ -301,33 +294,6 @@ class UNet:
     self._ctx_rows = R
 
   # ---- blocks ------------------------------------------------------------------------------
-  def _gn_conv(self, x, gn, conv, out, **kw):
-    """conv3x3(SiLU(GroupNorm(x))) (unet.py:383-384,390-392).  On large feature maps the
-    normalisation is folded into the halo-staged conv (applied once per element in LDS);
-    otherwise a separate normalise pass feeds the implicit-GEMM conv."""
-    B_, dt = self.buf, self.dtype
-    R, cin = x.shape[0], x.shape[-1]
-    key = ("gnconv", tuple(x.shape), x.stride(), tuple(out.shape), out.stride())
-    fused = self._fuse_cache.get(key)
-    if fused is None:
-      # fused = the halo tile to launch on: 0 = the library's own choice (only shapes that fill the
-      # chip), 21..23 = forced (fuse_groupnorm="force": every eligible shape, tests on tiny models)
-      fused = False
-      if self.fuse_groupnorm == "force":
-        fused = next((t for t in (21, 22, 23) if ops.conv3x3_prologue_supported(x, conv[0], out, tile=t)), False)
-      elif self.fuse_groupnorm and ops.conv3x3_prologue_supported(x, conv[0], out):
-        fused = True
-      self._fuse_cache[key] = fused
-    if fused:
-      sc = B_.get("gn_scale", (R, cin), torch.float32)
-      sh = B_.get("gn_shift", (R, cin), torch.float32)
-      ops.groupnorm_scale_shift(x, gn[0], gn[1], sc, sh, GN_EPS_RES, partial=self._gnp)
-      return ops.conv3x3(x, conv[0], out, bias=conv[1], a_scale=sc, a_shift=sh, a_silu=True,
-                         tile=0 if fused is True else fused, **kw)
-    t0 = B_.get("gn", tuple(x.shape), dt)
-    self._gn(x, gn, GN_EPS_RES, True, t0)
-    return ops.conv3x3(t0, conv[0], out, bias=conv[1], **kw)
-
   # ---- split-K products whose reduce is fused into the GroupNorm that consumes them ---------------
   # A split-K convolution leaves float32 slabs; its reduce + epilogue launch is followed, almost
   # everywhere in the U-Net, by the GroupNorm of exactly that tensor.  `_conv_deferred` launches only the
@@ -354,16 +320,6 @@ class UNet:
   def _res(self, r, x, tall, out):
     B_, dt = self.buf, self.dtype
     R, h, w, _ = x.shape
-    if self.fuse_groupnorm:               # halo-conv prologue path (opt-in): no deferred reduces
-      self._flush()
-      h1 = B_.get("h1", (R, h, w, r.cout), dt)
-      self._gn_conv(x, r.gn1, r.conv1, h1, addend=tall[:, r.temb_off:r.temb_off + r.cout])
-      res = x
-      if r.shortcut is not None:
-        res = B_.get("sc", (R, h, w, r.cout), dt)
-        ops.linear(x, r.shortcut[0], res, bias=r.shortcut[1])
-      self._gn_conv(h1, r.gn2, r.conv2, out, residual=res)
-      return out
     # GN1 first: it completes a deferred product that produced x (x is materialised by that launch)
     t0 = B_.get("gn", tuple(x.shape), dt)
     self._gn(x, r.gn1, GN_EPS_RES, True, t0)
@@ -545,7 +501,7 @@ class UNet:
       assert not pre_decrement
       tall = self._temb(R, t_rows, steps, index, shared_t)
     env = self._env(x, tall, out)
-    env["pair"] = bool(paired_rows and self._shared_prefix and R % 2 == 0 and self._lanes == 1 and not self.fuse_groupnorm
+    env["pair"] = bool(paired_rows and self._shared_prefix and R % 2 == 0 and self._lanes == 1
                        and self.in_blocks[0][0] == "res" and self.in_blocks[0][2] is not None)
     prog = env["prog"]
     n = self._lanes if (self._lanes > 1 and R % self._lanes == 0) else 1

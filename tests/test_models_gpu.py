@@ -90,20 +90,6 @@ def test_unet_forward(dev, dtype, unet_w):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_unet_forward_fused_groupnorm(dev, dtype, unet_w):
-  """GroupNorm+SiLU folded into the halo-staged conv (opt-in path) gives the same U-Net."""
-  from ldm_tf2_amd.unet import UNet
-  x, ctx = _inputs()
-  t = np.array([981, 981, 21, 500], dtype=np.int32)
-  ref = O.unet_forward(x, t, ctx, unet_w)
-  unet = UNet(**UNET_CFG, weights=unet_w, dtype=dtype, device=dev, context_dim=CTX_DIM,
-              fuse_groupnorm="force")       # forced halo tiles: the tiny shapes take the path too
-  got = unet(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(ctx))
-  assert any(unet._fuse_cache.values()), "no conv took the fused path"
-  check(got, ref, dtype, "unet (fused GroupNorm)")
-
-
-@pytest.mark.parametrize("dtype", DT)
 def test_text_encoder(dev, dtype, txt_w):
   from ldm_tf2_amd.transformer import TransformerModel
   g = np.random.default_rng(1)

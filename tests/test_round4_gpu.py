@@ -416,7 +416,7 @@ def test_plan_entry_that_cannot_run_falls_back(dev, tmp_path):
   add = torch.randn(B, Cout, generator=g).to(dev)
   res = torch.randn(B, H, H, Cout, generator=g).to(dev).to(torch.bfloat16)
   p = ops._conv_params(x, w, torch.empty(B, H, H, Cout, dtype=torch.bfloat16, device=dev), bias, 1, False, add, res,
-                       0, 0, None, None, False)
+                       0, 0)
   key = ops.plan_key(p)
   before = ops.plan_tables()
   f = tmp_path / "bad.json"
@@ -426,7 +426,7 @@ def test_plan_entry_that_cannot_run_falls_back(dev, tmp_path):
     want = torch.empty(B, H, H, Cout, dtype=torch.bfloat16, device=dev)
     ops.conv3x3(x, w, want, bias=bias, addend=add, residual=res)          # no table: the cost model's plan
     with ops.plan_scope(B, 1234, torch.bfloat16):
-      q = ops._conv_params(x, w, want, bias, 1, False, add, res, 0, 0, None, None, False)
+      q = ops._conv_params(x, w, want, bias, 1, False, add, res, 0, 0)
       assert ops.resolve_plan(q) and q.tile == 13                          # the entry is live in this scope
       got = torch.empty_like(want)
       ops.conv3x3(x, w, got, bias=bias, addend=add, residual=res)
