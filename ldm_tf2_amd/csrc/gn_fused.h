@@ -123,9 +123,21 @@ __global__ __launch_bounds__(NT, (SK ? (NT >= 1024 ? 4 : 2) : (MAXCH <= 8 || (MA
     const int64_t row0 = (int64_t)b * HW + pl;
     const float* src0 = sk.ws + row0 * sk.N + c0;
     const int64_t kstep = (int64_t)P * sk.N;                  // floats between a thread's consecutive chunks
-    constexpr int KB = MAXCH < 8 ? MAXCH : 8;
+    // KB chunks x SU splits = 8 chunk-loads in flight per round trip, as before, but no longer 8 x 1: a one-wave
+    // workgroup (the 8x8 / 4x4 levels: 2 - 6 chunks per thread, 4 - 12 splits) paid one memory round trip PER SPLIT
+    // -- 16 us for a 1.3 MB tensor -- and takes 2 x 4 (13.5 us); the larger slabs (2 splits, 6 - 11 chunks) take 4 x 2.  A batch
+    // of chunks none of whose pixels exist is skipped (workgroup-uniform); a split past the last one loads slab 0
+    // and adds nothing.  Summation order per element: slabs in split order, as ever.
+    constexpr int SU = NT == 64 ? 4 : 2;
+    constexpr int KBW = 8 / SU;                      // (4 x 4 on the one-wave form: 250 VGPRs, one wave per SIMD less: 15.0 vs 13.5 us)
+    constexpr int KB = MAXCH < KBW ? MAXCH : KBW;
 #pragma unroll
     for (int k0 = 0; k0 < MAXCH; k0 += KB) {
+      if (k0 > 0 && k0 * P >= HW) {                  // pl + k P >= HW for every thread and every k >= k0:
+#pragma unroll
+        for (int k = 0; k < KB; ++k) { u32x4 z = {0u, 0u, 0u, 0u}; v[k0 + k] = z; }   // nothing to sum (uniform)
+        continue;
+      }
       int64_t koff[KB];
       bool kval[KB];
       float f[KB][EPC];
@@ -141,19 +153,26 @@ __global__ __launch_bounds__(NT, (SK ? (NT >= 1024 ? 4 : 2) : (MAXCH <= 8 || (MA
         if (sk.residual && kval[k])
           rres[k] = *(const u32x4*)((const T*)sk.residual + (row0 + (int64_t)(k0 + k) * P) * sk.ldr + c0);
       }
-      for (int sp = 0; sp < sk.split; ++sp) {
-        const float* src = src0 + sp * sk.slab;
-        f32x4 t[KB][EPC / 4];
+      for (int sp = 0; sp < sk.split; sp += SU) {    // SU slabs' loads in flight, added in split order
+        f32x4 t[SU][KB][EPC / 4];
 #pragma unroll
-        for (int k = 0; k < KB; ++k)
+        for (int u = 0; u < SU; ++u) {
+          const float* src = src0 + (sp + u < sk.split ? sp + u : 0) * sk.slab;
 #pragma unroll
-          for (int q = 0; q < EPC / 4; ++q) t[k][q] = *(const f32x4*)(src + koff[k] + 4 * q);
+          for (int k = 0; k < KB; ++k)
 #pragma unroll
-        for (int k = 0; k < KB; ++k)
+            for (int q = 0; q < EPC / 4; ++q) t[u][k][q] = *(const f32x4*)(src + koff[k] + 4 * q);
+        }
 #pragma unroll
-          for (int q = 0; q < EPC / 4; ++q)
+        for (int u = 0; u < SU; ++u) {
+          const bool live = sp + u < sk.split;        // (uniform)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) f[k][4 * q + e] += kval[k] ? t[k][q][e] : 0.f;
+          for (int k = 0; k < KB; ++k)
+#pragma unroll
+            for (int q = 0; q < EPC / 4; ++q)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) f[k][4 * q + e] += (kval[k] && live) ? t[u][k][q][e] : 0.f;
+        }
       }
 #pragma unroll
       for (int k = 0; k < KB; ++k) {
