@@ -121,3 +121,9 @@ def test_halo_ring_candidates_follow_the_conv_geometry():
   assert not {15, 16} & tiles(kup, 32768, 640, 5760)
   assert not {15, 16} & tiles(k32.replace("dt1 odt1", "dt0 odt0"), 32768, 320, 2880, ops.F32)
   assert not {15, 16} & tiles(None, 32768, 320, 2880)
+  # a second A operand (" x2": the ResBlock shortcut inside the convolution, FF-out + proj_out folded) runs on the
+  # implicit-GEMM tiles only: neither the halo-staged nor the persistent tiles are offered for such a key
+  kx = "M32768 N320 K3840 b1 conv1 H32 W32 s1 u0 nlp0 act0 dt1 odt1 x2"
+  assert not {13, 14, 15, 16} & tiles(kx, 32768, 320, 3840) and 9 in tiles(kx, 32768, 320, 3840)
+  kd = "M8192 N640 K3200 b1 conv0 H0 W0 s0 u0 nlp0 act0 dt1 odt1 x2"
+  assert not {13, 14} & tiles(kd, 8192, 640, 3200)
