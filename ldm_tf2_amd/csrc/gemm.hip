@@ -512,13 +512,7 @@ extern "C" int ldm_gemm(const ldm_gemm_params* p, void* stream) {
     if (nsplit > g.ntiles) nsplit = g.ntiles;
     g.tiles_per_wg = cdiv(g.ntiles, nsplit);
     g.nsplit = cdiv(g.ntiles, g.tiles_per_wg);
-    if (nsplit_out) {
-      // a workgroup lies on ONE side of n_split: the same tiles per workgroup on both sides, rounded per side
-      g.ntiles1 = p->n_split / bn;
-      g.tiles_per_wg2 = g.tiles_per_wg;
-      g.nsplit1 = cdiv(g.ntiles1, g.tiles_per_wg);
-      g.nsplit = g.nsplit1 + cdiv(g.ntiles - g.ntiles1, g.tiles_per_wg2);
-    }
+    if (nsplit_out) g.ntiles1 = p->n_split / bn;         // (a workgroup's range of n-tiles may straddle it)
     dim3 grid3((unsigned)(g.panels * g.nsplit));
     hipStream_t s3 = (hipStream_t)stream;
     g.out_t = (char*)p->out2; g.ld_t = p->ld2; g.stride_t = p->stride2; g.rows_t = p->rows2; g.n_split = p->n_split;

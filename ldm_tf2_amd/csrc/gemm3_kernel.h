@@ -45,8 +45,7 @@ struct Gemm3Args {
   int64_t ld_t, stride_t;
   int rows_t;
   int n_split;        // EPI bit 7: columns >= n_split (whole n-tiles) take the transposed store, relative to n_split
-  int ntiles1, nsplit1, tiles_per_wg2;   // ... n-tiles below n_split, workgroups per panel that walk them
-                                         // (tiles_per_wg each), n-tiles per workgroup on the transposed side
+  int ntiles1;        // ... n-tiles below n_split
   const float* ln_cs; // EPI bit 6: column sums of the gamma-scaled weights (LayerNorm folded into the product)
   float ln_eps;
 #ifdef LDM_TOOLS_BUILD
@@ -77,9 +76,9 @@ struct Gemm3Args {
 //   bit 7 SPLIT output (with bit 5): n-tiles below n_split store row-major into `out`, the n-tiles from n_split on
 //         transposed into out_t (column n - n_split): the self-attention's q | k and V^T projections -- two
 //         products over the same LayerNorm'ed rows -- as ONE launch (one round of workgroups, one fill / drain
-//         instead of two).  A WORKGROUP lies on one side of n_split: the kernel body is instantiated once per side
-//         and the workgroup picks its instance at the top (a per-n-tile switch inside one body kept both
-//         epilogues' temporaries alive across the pipeline loop: 256 registers + 92 B of scratch against 190)
+//         instead of two).  The kernel body is instantiated once per side of n_split and a workgroup runs the
+//         instance(s) its range of n-tiles needs (a per-n-tile switch inside ONE body kept both epilogues'
+//         temporaries alive across the pipeline loop: 256 registers + 92 B of scratch against 190)
 constexpr int kEpiBias = 1, kEpiAdd = 2, kEpiRes = 4, kEpiTrans = 32, kEpiLn = 64, kEpiSplit = 128;
 constexpr int epi_code(bool bias, bool add, bool res, int act) { return (bias ? 1 : 0) | (add ? 2 : 0) | (res ? 4 : 0) | (act << 3); }
 
@@ -623,15 +622,18 @@ __global__ __launch_bounds__(512) void gemm3_kernel(Gemm3Args p) {
   }
   const int panel = bid / p.nsplit, sp = bid - panel * p.nsplit;
   if constexpr ((EPI & kEpiSplit) != 0) {
-    // workgroups 0 .. nsplit1 - 1 of a panel walk the row-major n-tiles, the others the transposed ones
-    if (sp < p.nsplit1) {
-      const int nt_begin = sp * p.tiles_per_wg;
-      const int ntl = min(p.ntiles1, nt_begin + p.tiles_per_wg) - nt_begin;
-      if (ntl > 0) gemm3_body<TN, MODE, EPI, false>(p, smem, panel, nt_begin, ntl);
-    } else {
-      const int nt_begin = p.ntiles1 + (sp - p.nsplit1) * p.tiles_per_wg2;
-      const int ntl = min(p.ntiles, nt_begin + p.tiles_per_wg2) - nt_begin;
-      if (ntl > 0) gemm3_body<TN, MODE, EPI, true>(p, smem, panel, nt_begin, ntl);
+    // a workgroup walks a contiguous range of the panel's n-tiles; the part below ntiles1 is row-major, the part
+    // from it on transposed.  A range that straddles ntiles1 runs the two instances of the body one after the other
+    // (the pipeline drains in between and the second instance takes its own row statistics): the n-tiles can then
+    // be dealt evenly whatever the two sides' sizes (6 + 3 n-tiles on 2 workgroups per panel at M = 32768)
+    const int nt_begin = sp * p.tiles_per_wg;
+    const int nt_end = min(p.ntiles, nt_begin + p.tiles_per_wg);
+    const int a_end = min(nt_end, p.ntiles1);
+    if (nt_begin < a_end) gemm3_body<TN, MODE, EPI, false>(p, smem, panel, nt_begin, a_end - nt_begin);
+    const int b_begin = max(nt_begin, p.ntiles1);
+    if (b_begin < nt_end) {
+      if (nt_begin < a_end) __syncthreads();               // every wave is done with the ring of the first instance
+      gemm3_body<TN, MODE, EPI, true>(p, smem, panel, b_begin, nt_end - b_begin);
     }
   } else {
     const int nt_begin = sp * p.tiles_per_wg;

@@ -137,7 +137,7 @@ class UNet:
                num_heads=8, *, weights=None, dtype=torch.float32, device="cuda:0",
                context_dim=1280, init="keras", seed=2, fuse_layernorm=False, fuse_qkv=True,
                split_qkv=True, small_conv_out=False, fold_layernorm=True, fold_min_rows=2048,
-               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=16384,
+               defer_reduce=True, matrix_softmax=True, gn_single_launch=True, fused_ffn=True, ffn_min_rows=24576, fused_tail=True, fused_xattn=True, fused_block=True, lanes=1, lane_levels=None, shared_prefix=True, merge_qkv=True, merge_qkv_max_rows=1 << 30,
                merge_shortcut=True, merge_ffproj=True, block_min_rows=12288):
     # fuse_layernorm: the transformer blocks' LayerNorms come out of the producing GEMM's epilogue
     # where its tile holds whole rows (C = 320).  Measured on MI355X at R=32: 11.02 vs 10.95 ms per
@@ -174,8 +174,8 @@ class UNet:
     self._merge_ffproj = bool(merge_ffproj)       # FF-out + proj_out as one folded product on the per-layer path (bf16; A/B: False)
     self._merge_shortcut = bool(merge_shortcut)   # ResBlock shortcut inside its second convolution's K loop (A/B: False)
     self._merge_qkv = bool(merge_qkv)             # LayerNorm-folded q | k | V^T as one launch (A/B: False = two)
-    # ... where a panel's workgroups can be dealt to the two sides of the launch evenly: at M = 32768 (128 panels,
-    # 2 workgroups each for 6 + 3 n-tiles) the one-sided workgroups would be 6 and 3 tiles long
+    # (a row limit from the first form of the launch, whose workgroups lay on one side of n_split and could not be
+    # balanced at M = 32768: 6 + 3 n-tiles on 2 workgroups per panel; ranges may straddle n_split now)
     self._merge_qkv_max_rows = int(merge_qkv_max_rows)
     self._shared_prefix = bool(shared_prefix)     # forward(paired_rows=True): the CFG pair's common prefix once (A/B: False)
     self._lanes = max(1, int(lanes))
