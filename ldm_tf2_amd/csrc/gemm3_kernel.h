@@ -337,9 +337,15 @@ __device__ __forceinline__ void gemm3_body(const Gemm3Args& p, char* smem, const
     const int g = lh;
     [[maybe_unused]] float ln_mu = 0.f, ln_r = 0.f;           // of row wm * 64 + lane (sums complete after n-tile 0)
     if constexpr (LN) {
+      // The contraction is PINNED (one fmul per moment, one explicit fma for E[x^2] - mean^2): this lambda is
+      // inlined at several places (in the pipeline loops and behind them) and, left to -ffp-contract=fast, the
+      // copies fused `q ik - mu mu` differently -- the variance of a row then differed in its last bit between a
+      // workgroup's last n-tile and its others, i.e. between two deals of n-tiles to workgroups (found in round 4:
+      // 8 - 46 of 25 M outputs on the other side of a bf16 rounding tie)
       const float ik = 1.0f / (float)p.K;
       ln_mu = ln_s * ik;
-      ln_r = rsqrtf(fmaxf(ln_q * ik - ln_mu * ln_mu, 0.f) + p.ln_eps);
+      const float ex2 = ln_q * ik;
+      ln_r = rsqrtf(fmaxf(__builtin_fmaf(-ln_mu, ln_mu, ex2), 0.f) + p.ln_eps);
     }
     if constexpr (TR) {
       const int n_t = SPLIT ? n_w - p.n_split : n_w;         // column of out_t

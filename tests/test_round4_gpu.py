@@ -259,16 +259,10 @@ def test_merged_qkv_launch_equals_the_two_launches(dev, R, T, C, H, S):
   vt1 = torch.zeros(R, hs, tp, dtype=BF, device=dev)
   ops.linear(xd, a_w, qk1, bias=a_b, ln_fold=(a_cs, 1e-5), out2=vt1)
   torch.cuda.synchronize()
-  if M * 3 * hs < (1 << 24):
-    assert torch.equal(qk1, qk0) and torch.equal(vt1, vt0)
-  else:
-    # 25 M outputs: the LayerNorm-folded persistent kernel is bit-reproducible for a GIVEN deal of n-tiles to
-    # workgroups, but between two deals a handful of outputs (measured: 6 + 4 here; 8 - 16 between 2 and 3 / 6
-    # workgroups per panel of the UNMERGED launch) land on the other side of a bf16 rounding tie -- last-bit, not
-    # a form error: bounded here at one bf16 ulp on < 1e-5 of the outputs
-    for a_, b_ in ((qk1, qk0), (vt1, vt0)):
-      d = (a_.float() - b_.float()).abs()
-      assert int((d != 0).sum()) <= 1e-5 * d.numel() and float((d / b_.float().abs().clamp_min(1e-3)).max()) <= 2.0 ** -7
+  # (bit for bit at 25 M outputs too: round 4 first saw 10 outputs on the other side of a bf16 rounding tie here -- the
+  # LayerNorm fold's variance was contracted differently in the inlined copies of the epilogue, so a row's rstd
+  # depended on whether its n-tile was a workgroup's last; the contraction is pinned in gemm3_kernel.h now)
+  assert torch.equal(qk1, qk0) and torch.equal(vt1, vt0)
   ln = O.layer_norm(x.float(), gamma, beta, eps=1e-5)
   want_qk = ln @ torch.cat([wq, wk], 0).t()
   want_v = (ln @ wv.t()).view(R, T, hs).permute(0, 2, 1)
@@ -414,6 +408,29 @@ def test_ffout_and_proj_out_as_one_folded_product(dev, M, C, tile, split):
   r, r2 = rel(out), rel(out2)
   print(f"FF-out + proj_out folded M={M} C={C} tile {tile} split {split}: rel {r:.3e} (two launches {r2:.3e})")
   assert torch.isfinite(out.float()).all() and r < 5e-3 and r <= r2 * 1.2
+
+
+def test_layernorm_fold_does_not_depend_on_the_deal_of_n_tiles(dev):
+  """The LayerNorm-folded persistent launch gives the same bits however its n-tiles are dealt to workgroups (1, 2, 3
+  or 6 per 256-row panel; split_k < 0 = workgroups per panel).  Round 4 found 8 - 46 of 25 M outputs differing by one
+  bf16 ulp between deals: `q ik - mu mu` was fused differently in the epilogue's inlined copies (-ffp-contract=fast),
+  so a row's variance depended on whether the n-tile was the workgroup's last."""
+  from ldm_tf2_amd import layout as L
+  BF = torch.bfloat16
+  M, C, N = 32768, 320, 768
+  g = torch.Generator().manual_seed(11)
+  x = (torch.randn(M, C, generator=g) * 1.5 + 0.5 * torch.randn(M, 1, generator=g)).to(BF).to(dev)
+  w = torch.randn(N, C, generator=g) * C ** -0.5
+  gamma, beta = 1.0 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+  wq, cs, bb = L.ln_fold(w, gamma.numpy(), beta.numpy(), torch.randn(N, generator=g).numpy(), BF, dev)
+  outs = []
+  for wg in (1, 2, 3, 6):
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    ops.linear(x, wq, out, bias=bb, ln_fold=(cs, 1e-5), tile=14, split_k=-wg)
+    outs.append(out)
+  torch.cuda.synchronize()
+  for o_ in outs[1:]:
+    assert torch.equal(o_, outs[0])
 
 
 def test_plan_entry_that_cannot_run_falls_back(dev, tmp_path):
