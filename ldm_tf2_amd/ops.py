@@ -410,7 +410,7 @@ def linear_ln_supported(n_out, dtype):
 
 
 def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_rows=0,
-           alpha=1.0, tile=0, split_k=0, ln=None, out2=None, ln_fold=None, x2=None):
+           alpha=1.0, tile=0, split_k=0, ln=None, out2=None, ln_fold=None, x2=None, defer_reduce=False):
   """out[..., n] = act(alpha * x[..., :] . wt[n, :] + bias[n] + addend[group]) + residual.
   x [..., K]; wt [N, K] contiguous; out [..., N] (N/2 wide for GEGLU).
   `ln=(gamma, beta, ln_out, eps)`: also writes ln_out = LayerNorm(out) (same shape/dtype).
@@ -418,6 +418,7 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
   stored TRANSPOSED per group of T = M/G rows (q|k into `out`, v into the attention kernel's
   V^T [rows, heads*Sp, T] in one launch).
   `x2` [..., K2]: out = x . wt[:, :K]^T + x2 . wt[:, K:]^T + ...: two products over the same rows as ONE launch.
+  `defer_reduce`: as conv3x3's -- a split-K plan leaves its slabs to the caller (returns a PendingReduce or None).
   `ln_fold=(cs, eps)`: out = LayerNorm(x) . W^T + b with the normalisation folded into the product:
   `wt` holds gamma (.) W, `bias` holds b + W beta, cs[n] = sum_k wt[n, k] (layout.ln_fold); the kernel
   derives the row statistics itself (bf16, persistent tiles)."""
@@ -459,6 +460,9 @@ def linear(x, wt, out, bias=None, act=ACT_NONE, residual=None, addend=None, add_
     cs, eps = ln_fold
     assert bias is not None and tuple(cs.shape) == (N,) and cs.is_contiguous()
     p.ln_cs, p.ln_eps = _ptr(_f32(cs, "ln_fold column sums")), float(eps)
+  if defer_reduce:
+    # -> PendingReduce when the plan splits K (the caller owes `finish` or a consuming groupnorm), else None
+    return _gemm_deferred(p, x.device, out, (x, wt, bias, addend, residual, x2))
   _gemm(p, x.device)
   return out
 

@@ -467,7 +467,11 @@ class UNet:
     if st.ffp is not None and self._merge_ffproj:
       # y = h + FF-out(ff) and proj_out(y) + x are two linear layers with a residual between them: ONE product over
       # (ff | h) with the folded weights (Wp W2 | Wp) -- no proj_out launch, no y tensor (unet.py:313, :363-365)
-      ops.linear(ff, st.ffp[0], out, bias=st.ffp[1], residual=x, x2=ha)
+      # (its split-K reduce is left to the GroupNorm that reads `out` next -- the following ResBlock's, on the way
+      # down -- like a convolution's; whatever else comes next flushes it as a plain reduce)
+      self._flush()
+      r = ops.linear(ff, st.ffp[0], out, bias=st.ffp[1], residual=x, x2=ha, defer_reduce=self._defer_reduce)
+      self._pend = r if isinstance(r, ops.PendingReduce) else None
       return out
     ops.linear(ff, st.ff_out[0], hb, bias=st.ff_out[1], residual=ha)
     ops.linear(hb, st.proj_out[0], out, bias=st.proj_out[1], residual=x)
