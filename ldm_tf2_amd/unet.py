@@ -606,7 +606,7 @@ class UNet:
     (cat[j] = input of output block j = [previous output | skip n_in - j]), the final feature map, x, out.
     A step is (kind, index, level); a branch executes a range of steps on its row slice of these buffers."""
     R, h, w, _ = x.shape
-    B_, dt, mc = self.buf, self.dtype, self._model_channels
+    B_, dt = self.buf, self.dtype
     n_in = len(self.in_blocks)
     prev_ch = [self.mid[2].cout] + [b[0].cout for b in self.out_blocks[:-1]]
     cats = []
