@@ -635,7 +635,15 @@ class UNet:
     n_in = len(self.in_blocks)
     skip_dst = lambda i: sl(cats[n_in - i])[..., prev_ch[n_in - i]:]
     if kind == "conv_in":
-      ops.conv3x3_small(x, self.conv_in[0], self.conv_in[1], skip_dst(0))
+      if env.get("pair") and rows is None:
+        # a CFG pair: both halves of x are the same rows -- the convolution once, its output copied (the skip
+        # tensor is read with all rows by the last output block)
+        half = R // 2
+        d0 = skip_dst(0)
+        ops.conv3x3_small(x[:half], self.conv_in[0], self.conv_in[1], d0[:half])
+        ops.cast(d0[:half], d0[half:])
+      else:
+        ops.conv3x3_small(x, self.conv_in[0], self.conv_in[1], skip_dst(0))
     elif kind == "in":
       cur, dst = skip_dst(idx), skip_dst(idx + 1)
       blk = self.in_blocks[idx]
