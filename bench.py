@@ -372,15 +372,18 @@ def main():
     peak = PEAK_TFLOPS[args.dtype]
     # HBM-side bytes of the family per U-Net step from the committed PMC passes (same workload;
     # separate rocprofv3 --pmc runs, gfx950 FETCH_SIZE correction applied by tools/pmc_family.py)
-    traffic = None
+    traffic, traffic_src = None, ""
     tjs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
     tj = os.path.join(ROOT, "profiles", tjs[-1]) if tjs else ""     # the latest round's PMC passes
     if args.dtype == "bf16" and lat == 32 and B == 16 and os.path.isfile(tj):
-      traffic = json.load(open(tj)).get("hbm_bytes_per_eval")
+      tjd = json.load(open(tj))
+      traffic = tjd.get("hbm_bytes_per_eval")
+      traffic_src = f"; measured at commit {tjd['measured_at_commit']} on {tjd.get('measured_on', 'a pool box')}" if tjd.get("measured_at_commit") else ""
     roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
                 "traffic_unit": ("HBM bytes per U-Net step for this kernel family, from the committed PMC passes of the same "
-                                 f"workload (profiles/{os.path.basename(tj) if tj else '-'}; tools/profile_round.sh reproduces them)"),
+                                 f"workload (profiles/{os.path.basename(tj) if tj else '-'}; tools/profile_round.sh reproduces them)"
+                                 + (traffic_src if traffic is not None else "")),
                 "kernel": ("every launch of ldm_gemm: gemm_kernel<T,BM,BN,WM,WN,MODE,MF,ST,NS> + gemm3_kernel<TN,MODE,EPI> (Dense/1x1/"
                            "projection GEMMs incl. the LayerNorm-folded ones + implicit-GEMM 3x3 convs) + their split-K reduces (plain "
                            "launches, and the extra time of the GroupNorm launches that complete a deferred reduce) + the row-panel "
